@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/s of one training step (forward + rd_loss + backward + Adam step)
+of the hot path on synthetic 256x256 RGB batches, batch 32 per GPU.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3k|4|5] [--no-cpu-baseline]
+
+N > 1 is launched by the driver as  python -m torch.distributed.run --nproc-per-node N ... bench.py
+--gpus N ...: one rank per GPU, images sharded (32 per rank, weak scaling), one RCCL all-reduce of
+the gradients per step.  Rank 0 prints ONE JSON line.
+
+Workload (config 2, BASELINE.json configs[1]): JointAutoregressiveHierarchical(192, K=1)
+(the nearest reference surface to "scale hyperprior capacity 192"), B=32,
+256x256, fp32, lambda=0.01, default-initialised weights (seed 0), x = rand (seed 1234+rank).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FP32_MFMA_PEAK_TF = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 = vector fp32 rate
+HBM_PEAK_GBS = 8000.0
+
+CONFIGS = {
+    # name: (model kind, M, K, B per GPU, H, W, lambda)
+    "2": ("jah", 192, 1, 32, 256, 256, 0.01),
+    "3k": ("jah", 128, 3, 32, 256, 256, 0.01),   # config 3's model in fp32 (bf16 storage is a later round)
+    "4": ("jah", 192, 3, 32, 256, 256, 0.01),
+    "5": ("jah", 192, 3, 16, 512, 512, 0.01),
+}
+
+
+def cpu_baseline(M, K, H, W, lam, budget_s=25.0):
+    """The CPU oracle (oracle/lic_oracle.c, 'port') timed on this host's cores on a bounded sample
+    of the same workload: one fwd + rd_loss + bwd of ONE image batch slice."""
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import golden_recipe as R
+    import neural_image_compression_amd as nic
+    from oracle import oracle as O
+    cores = len(os.sched_getaffinity(0))
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    m = nic.JointAutoregressiveHierarchical(M, K)
+    ks = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
+    st = R.make_state(ks, 0)
+    B = 1
+    x = R.make_image(B, H, W, 1234)
+    uz, uy = R.make_noise((B, M, H // 64, W // 64), 1), R.make_noise((B, M, H // 16, W // 16), 2)
+    O.lib()
+    n, t0 = 0, time.perf_counter()
+    while True:
+        O.model_forward(dict(st), x, M, K, "5x5", training=True, noise=(uz, uy), lambda_rd=lam, backward=True)
+        n += B
+        el = time.perf_counter() - t0
+        if el > budget_s or n >= 4:
+            break
+    return {"value": round(n / el, 4), "unit": "images/s", "cores": cores, "kind": "port",
+            "sample": f"{n} image(s) {H}x{W}, fwd+rd_loss+bwd, JAH M={M} K={K}, fp32 C oracle (OpenMP)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="2", choices=sorted(CONFIGS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile-events", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import neural_image_compression_amd as nic
+    from neural_image_compression_amd import functional as F_
+    from neural_image_compression_amd.parallel import GradientAllReducer, broadcast_parameters
+
+    kind, M, K, B, H, W, lam = CONFIGS[args.config]
+    torch.manual_seed(0)
+    model = nic.JointAutoregressiveHierarchical(M, K).to(dev)
+    broadcast_parameters(model)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    reducer = GradientAllReducer(model.parameters()) if world > 1 else None
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    x = torch.rand(B, 3, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        out = model(x)
+        res = nic.rd_loss(out, x, lam, sync=False)
+        res["loss"].backward()
+        if reducer is not None:
+            reducer.finish()
+        opt.step()
+        return res
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    if not args.no_profile_events:
+        F_.PROFILE = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    fence()
+    el = time.perf_counter() - t0
+    prof, F_.PROFILE = F_.PROFILE, None
+    t = torch.tensor([el], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t.item())
+
+    if rank == 0:
+        ms = el / args.steps * 1e3
+        value = world * B * args.steps / el
+        line = {
+            "metric": "images/sec (256x256 RGB, batch 32) fwd+bwd" if (H, W, B) == (256, 256, 32)
+            else f"images/sec ({H}x{H} RGB, batch {B}) fwd+bwd",
+            "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"cfg{args.config}: JointAutoregressiveHierarchical(M={M},K={K}) "
+                                   f"fwd+rd_loss(lambda={lam})+bwd+Adam, {B}x3x{H}x{W} per GPU, fp32",
+                       "global_batch": world * B, "parallelism": f"dp{world}",
+                       "loss": round(float(res["loss"]), 6)},
+        }
+        if prof:
+            # per-kernel totals from HIP events recorded around every MFMA launch of the timed region
+            agg = {}
+            for name, flops, abytes, e0, e1 in prof:
+                a = agg.setdefault(name, [0, 0.0, 0.0, 0.0])
+                a[0] += 1
+                a[1] += e0.elapsed_time(e1) * 1e-3
+                a[2] += flops
+                a[3] += abytes
+            dom = max(agg, key=lambda k: agg[k][1])
+            n, secs, flops, abytes = agg[dom]
+            ach = flops / secs / 1e12
+            line["roofline"] = {
+                "kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TF,
+                "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TF, 4), "traffic": None,
+                "launches": n, "avg_launch_ms": round(secs / n * 1e3, 4),
+                "alg_gflop_per_launch": round(flops / n / 1e9, 3),
+                "hbm_frac_of_alg_bytes": round(abytes / secs / 1e9 / HBM_PEAK_GBS, 4),
+            }
+            line["kernels"] = {k: {"launches": v[0], "ms_per_step": round(v[1] / args.steps * 1e3, 3),
+                                   "tflops": round(v[2] / max(v[1], 1e-12) / 1e12, 2)} for k, v in agg.items()}
+            mfma_s = sum(v[1] for v in agg.values())
+            line["mfma_kernel_share_of_step"] = round(mfma_s / el, 4)
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                line["cpu_baseline"] = cpu_baseline(M, K, H, W, lam)
+            except Exception as e:  # the baseline is a report, never a reason to lose the GPU number
+                line["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": 0, "kind": "port",
+                                        "sample": f"failed: {e!r}"}
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,209 @@
+/*
+ * lic.h -- C ABI of liblic_hip.so: the MI355X (gfx950) implementation of the
+ * analysis/synthesis + hyperprior + likelihood + rate-distortion hot path of
+ * achraf-15/neural_image_compression.
+ *
+ * The reference has no FFI: its "operator API" for this path is torch's ATen ops reached from
+ * the nn.Module surface.  Each entry point below names the reference call
+ * site(s) whose device arithmetic it replaces (paths relative to the reference repo root).
+ *
+ * Conventions
+ *  - All pointers are DEVICE pointers to fp32 unless stated.  Activations are NHWC: element
+ *    (b,h,w,c) of a tensor with row pitch `ld` (floats per pixel, ld >= C) lives at
+ *    ((b*H + h)*W + w)*ld + c.  `ld` lets two producers write disjoint channel ranges of one
+ *    buffer (the reference's torch.cat([phi, psi]), Models.py:73, is never materialised).
+ *  - The library never allocates, frees or synchronises; every launch goes to `stream`
+ *    (a hipStream_t passed as void*), so every call is hipGraph-capturable.  Workspaces are
+ *    caller-owned; sizes come from the *_workspace_bytes queries.
+ *  - Return value: LIC_OK (0) or a negative lic_status.  Nothing throws or exits.
+ *  - Re-entrant: no global mutable state; safe to call from autograd's backward thread.
+ */
+#ifndef LIC_H
+#define LIC_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LIC_ABI_VERSION 1
+
+typedef void* lic_stream_t; /* hipStream_t */
+
+enum lic_status {
+  LIC_OK = 0,
+  LIC_ERR_INVALID = -1,     /* bad argument (null pointer, non-positive size, ...) */
+  LIC_ERR_UNSUPPORTED = -2, /* geometry outside what the kernels implement */
+  LIC_ERR_LAUNCH = -3,      /* hipLaunchKernel failed; see lic_last_hip_error() */
+  LIC_ERR_WORKSPACE = -4    /* workspace too small */
+};
+
+/* epilogues of lic_igemm (fused into the producing kernel) */
+enum lic_epilogue {
+  LIC_EPI_NONE = 0,           /* v = acc + bias                                              */
+  LIC_EPI_LEAKY = 1,          /* v = leaky(acc + bias); with res: out2 = v + res            */
+  LIC_EPI_MUL_LEAKY_MASK = 2, /* v = acc * (aux > 0 ? 1 : slope)  (grad through in-place LeakyReLU) */
+  LIC_EPI_GDN = 3,            /* n = acc + bias; out2 = n; v = aux * rsqrt(n)                 */
+  LIC_EPI_IGDN = 4,           /* n = acc + bias; out2 = n; v = aux * sqrt(n)                  */
+  LIC_EPI_GDN_BWD = 5,        /* v = aux * rsqrt(aux3) + 2 * aux2 * acc                       */
+  LIC_EPI_IGDN_BWD = 6        /* v = aux * sqrt(aux3)  + 2 * aux2 * acc                       */
+  /* for every epilogue except LEAKY a non-null `res` is added to v before the store */
+};
+
+/* ------------------------------------------------------------------------------------------
+ * lic_igemm -- implicit-GEMM convolution family on fp32 MFMA (v_mfma_f32_32x32x2_f32).
+ *   rows  = output pixels, cols = output channels, K = live taps x input channels.
+ *   transposed == 0:  out[b,oh,ow,:] = sum_{r,s} in[b, oh*stride-pad+r, ow*stride-pad+s, :] . W[r,s]
+ *   transposed == 1:  out[b,oy,ox,:] = sum_{r,s : (oy+pad-r) % stride == 0 ...}
+ *                                       in[b,(oy+pad-r)/stride,(ox+pad-s)/stride,:] . W[r,s]
+ *   W is the packed weight [kh*kw][Cin][Cout] (see lic_permute3 for producing it).
+ * Replaces: nn.Conv2d / nn.ConvTranspose2d forward and their input gradients
+ *   (Components.py:10-16,39-45,69-73,99-103; Layers.py:21,38,40,43,74,76,99,101,103;
+ *   ParametersModels.py:22-34; ContextModels.py:19-20 via tap_mask), the GDN/IGDN channel
+ *   contraction (compressai GDN at Components.py:11,13,15,40,42,44; Layers.py:41,75) with
+ *   prologue=1 (square the input), nn.LeakyReLU (Components.py:70,72,100,102; Layers.py:39,73,100;
+ *   ParametersModels.py:23,25) and the residual adds (Layers.py:57,85,118) as epilogues.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct lic_igemm_desc {
+  const float* in;
+  const float* w;
+  const float* bias; /* [Cout] or NULL */
+  float* out;
+  float* out2; /* secondary output (GDN norm, LEAKY+res sum) or NULL */
+  const float* aux;
+  const float* aux2;
+  const float* aux3;
+  const float* res;
+  int64_t in_ld, out_ld, out2_ld, aux_ld, aux2_ld, aux3_ld, res_ld;
+  int32_t B, Hi, Wi, Cin;
+  int32_t Ho, Wo, Cout;
+  int32_t kh, kw, stride, pad;
+  int32_t transposed;
+  int32_t prologue; /* 0: none, 1: square the gathered input */
+  int32_t epilogue; /* enum lic_epilogue */
+  uint32_t tap_mask; /* bit (r*kw+s) set = tap is live; 0 = all taps (kh*kw <= 32) */
+  float slope;       /* LeakyReLU negative slope */
+} lic_igemm_desc;
+
+int lic_igemm(const lic_igemm_desc* d, lic_stream_t stream);
+/* which workgroup tile lic_igemm will launch for `d` (kernel name igemm_kernel<BM,BN>) and how
+ * many multiply-adds it will issue on live taps: lets a profiler attribute time and FLOPs. */
+int lic_igemm_plan(const lic_igemm_desc* d, int32_t* BM, int32_t* BN, int64_t* live_macs);
+
+/* ------------------------------------------------------------------------------------------
+ * lic_wgrad -- weight-gradient contraction over pixels on fp32 MFMA, split-K + slab reduce.
+ *   P ("plain") lives on the small grid [B,Hs,Ws,Cp]; G ("gathered") on the large grid
+ *   [B,Hl,Wl,Cg] sampled at (hs*stride-pad+r, ws*stride-pad+s).
+ *   R[tap][m][n] = sum_{b,hs,ws} (g_is_row ? G : P)[..m] * (g_is_row ? P : G)[..n]
+ *   dst[m*dst_sm + n*dst_sn + tap*dst_stap] = scale * R[tap][m][n]
+ * Replaces: autograd's weight gradients of every conv / convT / 1x1 on the path and the
+ *   dgamma contraction of GDN (sq_g = 1 squares G on load).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct lic_wgrad_desc {
+  const float* p;
+  const float* g;
+  float* dst;
+  int64_t p_ld, g_ld;
+  int64_t dst_sm, dst_sn, dst_stap;
+  int32_t B, Hs, Ws, Cp;
+  int32_t Hl, Wl, Cg;
+  int32_t kh, kw, stride, pad;
+  int32_t g_is_row;
+  int32_t sq_p, sq_g;
+  float scale;
+} lic_wgrad_desc;
+
+size_t lic_wgrad_workspace_bytes(const lic_wgrad_desc* d);
+int lic_wgrad(const lic_wgrad_desc* d, void* workspace, size_t workspace_bytes, lic_stream_t stream);
+
+/* column sums over pixels: out[c] = scale * sum_p in[p*ld + c]  (bias gradients, GDN dbeta) */
+size_t lic_colsum_workspace_bytes(int64_t P, int32_t C);
+int lic_colsum(const float* in, int64_t ld, int64_t P, int32_t C, float scale, float* out,
+               void* workspace, size_t workspace_bytes, lic_stream_t stream);
+
+/* generic 3-D strided copy: dst[i*d0+j*d1+k*d2] = src[i*s0+j*s1+k*s2]  (weight re-packing) */
+int lic_permute3(const float* src, float* dst, int32_t n0, int32_t n1, int32_t n2, int64_t s0,
+                 int64_t s1, int64_t s2, int64_t d0, int64_t d1, int64_t d2, lic_stream_t stream);
+
+/* 3-channel layers (image side): patches <-> columns, C small.
+ * im2col:  col[(b,oh,ow)][(r*kw+s)*C + c] = x[b, oh*stride-pad+r, ow*stride-pad+s, c] (0 outside),
+ *          columns [kh*kw*C, Kpad) are zero.       (stem conv Components.py:10, Layers.py:38,43)
+ * col2im:  out[b,oy,ox,c] = bias[c] + sum_{r,s} col[(b,ih,iw)][(r*kw+s)*C + c] with
+ *          oy = ih*stride-pad+r.                    (last convT Components.py:45, :60)            */
+int lic_im2col(const float* x, float* col, int32_t B, int32_t H, int32_t W, int32_t C, int32_t Ho,
+               int32_t Wo, int32_t kh, int32_t kw, int32_t stride, int32_t pad, int32_t Kpad,
+               lic_stream_t stream);
+int lic_col2im(const float* col, const float* bias, float* out, int32_t B, int32_t Hi, int32_t Wi,
+               int32_t C, int32_t Ho, int32_t Wo, int32_t kh, int32_t kw, int32_t stride,
+               int32_t pad, int32_t Kpad, lic_stream_t stream);
+
+/* ---- elementwise ------------------------------------------------------------------------- */
+/* w[i] *= mask[i]  (ContextModels.py:19, in place) */
+int lic_mul_inplace(float* w, const float* mask, int64_t n, lic_stream_t stream);
+/* dx = y > 0 ? dy : slope*dy  (LeakyReLU(inplace=True) backward from its output) */
+int lic_leaky_bwd(const float* y, const float* dy, float* dx, int64_t n, float slope,
+                  lic_stream_t stream);
+/* out = max(p,bound)^2 - pedestal  (compressai NonNegativeParametrizer forward) */
+int lic_gdn_reparam(const float* p, float* out, int64_t n, float bound, float pedestal,
+                    lic_stream_t stream);
+/* dp = pass ? dout*2*max(p,bound) : 0, pass = (p >= bound) | (that product < 0)  (LowerBound bwd) */
+int lic_gdn_reparam_bwd(const float* p, const float* dout, float* dp, int64_t n, float bound,
+                        lic_stream_t stream);
+/* t = dL/dnorm: inverse ? 0.5*g*x*rsqrt(n) : -0.5*g*x*rsqrt(n)/n   (dense [n] tensors) */
+int lic_gdn_dnorm(const float* g, const float* x, const float* norm, float* t, int64_t n,
+                  int32_t inverse, lic_stream_t stream);
+/* training: out = v + (u - 0.5); eval: out = rint(v)   (Models.py:55-64) */
+int lic_quantize(const float* v, const float* u, float* out, int64_t n, int32_t training,
+                 lic_stream_t stream);
+
+/* ---- entropy models (NHWC, P = B*h*w pixels) ------------------------------------------------ */
+/* ParametersModels.py:43-64.  raw/out rows hold G*K*M channels (G = 2 if K == 1 else 3):
+ * K==1: [mu | sigma]; K>1: [w | mu | sigma] with channel k*M+m inside each third. */
+int lic_entropy_params_fwd(const float* raw, float* out, int64_t P, int32_t M, int32_t K,
+                           lic_stream_t stream);
+int lic_entropy_params_bwd(const float* raw, const float* out, const float* dout, float* draw,
+                           int64_t P, int32_t M, int32_t K, lic_stream_t stream);
+/* EntropyModels.py:188-233 + clamp :29-31 + log Models.py:87.  x,p,logp: [P][M]; params as above.
+ * dp / dlogp may be NULL (treated as zero). */
+int lic_gmm_likelihood_fwd(const float* x, const float* params, float* p, float* logp, int64_t P,
+                           int32_t M, int32_t K, float bound, lic_stream_t stream);
+int lic_gmm_likelihood_bwd(const float* x, const float* params, const float* dp,
+                           const float* dlogp, float* dx, float* dparams, int64_t P, int32_t M,
+                           int32_t K, float bound, lic_stream_t stream);
+/* EntropyModels.py:49-151.  fe_params: [C][43] packed = matrices (3,9,9,3) | biases (3,3,3,1) |
+ * factors (3,3,3), each in the reference's row-major (out,in) order.  x,p,logp: [P][C]. */
+#define LIC_FE_NPARAM 43
+int lic_factorized_fwd(const float* x, const float* fe_params, float* p, float* logp, int64_t P,
+                       int32_t C, float bound, lic_stream_t stream);
+int lic_factorized_bwd(const float* x, const float* fe_params, const float* dp, const float* dlogp,
+                       float* dx, float* dfe_params, int64_t P, int32_t C, float bound,
+                       lic_stream_t stream);
+/* channel_logits_cumulative (EntropyModels.py:153-169): out[i] = L_ch(xs[i]) */
+int lic_factorized_channel_logits(const float* fe_params, int32_t ch, const float* xs, float* out,
+                                  int64_t n, lic_stream_t stream);
+
+/* ---- rate-distortion loss (RateDistortionLoss.py:5-49) ---------------------------------------
+ * Per-image element counts ny, nz, nx; images are contiguous blocks (layout-agnostic sums).
+ * out[0..8] = loss, bpp_y, bpp_z, bpp_total, mse, psnr, bits_y, bits_z, bits_total;
+ * out[16 .. 16+B) = mse_per_image; out[16+B .. 16+2B) = psnr_per_image. */
+size_t lic_rd_loss_workspace_bytes(int32_t B);
+int lic_rd_loss_fwd(const float* logp_y, int64_t ny, const float* logp_z, int64_t nz,
+                    const float* x_hat, const float* x, int64_t nx, int32_t B, int64_t num_pixels,
+                    float lambda_rd, float* out, void* workspace, size_t workspace_bytes,
+                    lic_stream_t stream);
+/* gl: device pointer to the upstream gradient of `loss` (a single float) */
+int lic_rd_loss_bwd(const float* x_hat, const float* x, int64_t ny, int64_t nz, int64_t nx,
+                    int32_t B, int64_t num_pixels, float lambda_rd, const float* gl, float* dlogp_y,
+                    float* dlogp_z, float* dx_hat, lic_stream_t stream);
+
+/* ---- misc ---------------------------------------------------------------------------------- */
+int lic_version(void);        /* LIC_ABI_VERSION */
+int lic_last_hip_error(void); /* hipError_t of the most recent failed launch on this thread */
+const char* lic_arch(void);   /* "gfx950" */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LIC_H */

@@ -1,0 +1,106 @@
+"""ctypes binding of liblic_hip.so (C ABI declared in include/lic.h).
+
+There is NO fallback: if the shared library is missing or a launch fails this raises.  The
+library is built in-tree by `__graft_entry__.build()` / `make -C neural_image_compression_amd/csrc`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblic_hip.so")
+
+# enum lic_epilogue
+EPI_NONE, EPI_LEAKY, EPI_MUL_LEAKY_MASK, EPI_GDN, EPI_IGDN, EPI_GDN_BWD, EPI_IGDN_BWD = range(7)
+FE_NPARAM = 43
+
+_vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
+
+
+class IgemmDesc(C.Structure):
+    _fields_ = [("in_", _vp), ("w", _vp), ("bias", _vp), ("out", _vp), ("out2", _vp), ("aux", _vp),
+                ("aux2", _vp), ("aux3", _vp), ("res", _vp),
+                ("in_ld", _i64), ("out_ld", _i64), ("out2_ld", _i64), ("aux_ld", _i64),
+                ("aux2_ld", _i64), ("aux3_ld", _i64), ("res_ld", _i64),
+                ("B", _i32), ("Hi", _i32), ("Wi", _i32), ("Cin", _i32),
+                ("Ho", _i32), ("Wo", _i32), ("Cout", _i32),
+                ("kh", _i32), ("kw", _i32), ("stride", _i32), ("pad", _i32),
+                ("transposed", _i32), ("prologue", _i32), ("epilogue", _i32),
+                ("tap_mask", C.c_uint32), ("slope", _f32)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [("p", _vp), ("g", _vp), ("dst", _vp),
+                ("p_ld", _i64), ("g_ld", _i64),
+                ("dst_sm", _i64), ("dst_sn", _i64), ("dst_stap", _i64),
+                ("B", _i32), ("Hs", _i32), ("Ws", _i32), ("Cp", _i32),
+                ("Hl", _i32), ("Wl", _i32), ("Cg", _i32),
+                ("kh", _i32), ("kw", _i32), ("stride", _i32), ("pad", _i32),
+                ("g_is_row", _i32), ("sq_p", _i32), ("sq_g", _i32), ("scale", _f32)]
+
+
+# name -> (restype, argtypes); every symbol declared in include/lic.h
+SIGNATURES = {
+    "lic_igemm": (C.c_int, [C.POINTER(IgemmDesc), _vp]),
+    "lic_igemm_plan": (C.c_int, [C.POINTER(IgemmDesc), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i64)]),
+    "lic_wgrad_workspace_bytes": (_sz, [C.POINTER(WgradDesc)]),
+    "lic_wgrad": (C.c_int, [C.POINTER(WgradDesc), _vp, _sz, _vp]),
+    "lic_colsum_workspace_bytes": (_sz, [_i64, _i32]),
+    "lic_colsum": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _vp, _vp, _sz, _vp]),
+    "lic_permute3": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i64, _vp]),
+    "lic_im2col": (C.c_int, [_vp, _vp] + [_i32] * 11 + [_vp]),
+    "lic_col2im": (C.c_int, [_vp, _vp, _vp] + [_i32] * 11 + [_vp]),
+    "lic_mul_inplace": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "lic_leaky_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp]),
+    "lic_gdn_reparam": (C.c_int, [_vp, _vp, _i64, _f32, _f32, _vp]),
+    "lic_gdn_reparam_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp]),
+    "lic_gdn_dnorm": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "lic_quantize": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
+    "lic_entropy_params_fwd": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
+    "lic_entropy_params_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "lic_gmm_likelihood_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp]),
+    "lic_gmm_likelihood_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _f32, _vp]),
+    "lic_factorized_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
+    "lic_factorized_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
+    "lic_factorized_channel_logits": (C.c_int, [_vp, _i32, _vp, _vp, _i64, _vp]),
+    "lic_rd_loss_workspace_bytes": (_sz, [_i32]),
+    "lic_rd_loss_fwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i64, _f32, _vp, _vp, _sz, _vp]),
+    "lic_rd_loss_bwd": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i32, _i64, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "lic_version": (C.c_int, []),
+    "lic_last_hip_error": (C.c_int, []),
+    "lic_arch": (C.c_char_p, []),
+}
+
+_lib = None
+
+
+class LicError(RuntimeError):
+    pass
+
+
+def load():
+    """Load liblic_hip.so (raises LicError when it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LicError(
+                f"{LIB_PATH} not found: the HIP extension is not built. Run "
+                "`python -c 'import __graft_entry__ as g; g.build()'` (or make -C "
+                "neural_image_compression_amd/csrc). There is no CPU fallback.")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)  # AttributeError if the ABI and the header diverge
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+_STATUS = {-1: "LIC_ERR_INVALID", -2: "LIC_ERR_UNSUPPORTED", -3: "LIC_ERR_LAUNCH", -4: "LIC_ERR_WORKSPACE"}
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        extra = f" (hipError {load().lic_last_hip_error()})" if rc == -3 else ""
+        raise LicError(f"{what} failed: {_STATUS.get(rc, rc)}{extra}")

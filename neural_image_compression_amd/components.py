@@ -1,0 +1,113 @@
+"""Analysis / synthesis / hyper stacks with the reference's class names, constructor
+signatures and `net.<i>` state-dict keys (reference: Components.py:6-122).
+`LatentSpaceTransform` (Components.py:125-153) is out of scope: it cannot execute upstream
+(SURVEY.md section 0)."""
+from __future__ import annotations
+
+import torch.nn as nn
+
+from .layers import (Conv2d, ConvTranspose2d, GDN, LeakyReLU, ResidualBlock, ResidualBlockUpsample,
+                     ResidualBlockWithStride, TransposedDeconv3x3, run_fused)
+
+
+class _Stack(nn.Module):
+    def forward(self, x):
+        return run_fused(self.net, x)
+
+
+class Encoder5x5(_Stack):
+    def __init__(self, latent_channels=192):
+        super().__init__()
+        M = latent_channels
+        self.net = nn.Sequential(
+            Conv2d(3, M, kernel_size=5, stride=2, padding=2), GDN(M, beta_min=1e-6, gamma_init=.1),
+            Conv2d(M, M, kernel_size=5, stride=2, padding=2), GDN(M, beta_min=1e-6, gamma_init=.1),
+            Conv2d(M, M, kernel_size=5, stride=2, padding=2), GDN(M, beta_min=1e-6, gamma_init=.1),
+            Conv2d(M, M, kernel_size=5, stride=2, padding=2),
+        )
+
+
+class Encoder3x3(_Stack):
+    def __init__(self, latent_channels=192):
+        super().__init__()
+        M = latent_channels
+        self.net = nn.Sequential(
+            ResidualBlockWithStride(3, M, stride=2), ResidualBlock(M, M),
+            ResidualBlockWithStride(M, M, stride=2), ResidualBlock(M, M),
+            ResidualBlockWithStride(M, M, stride=2), ResidualBlock(M, M),
+            Conv2d(M, M, kernel_size=3, stride=2, padding=1),
+        )
+
+
+class Decoder5x5(_Stack):
+    def __init__(self, latent_channels=192):
+        super().__init__()
+        M = latent_channels
+        ct = lambda ci, co: ConvTranspose2d(ci, co, kernel_size=5, stride=2, padding=2, output_padding=1)
+        self.net = nn.Sequential(
+            ct(M, M), GDN(M, inverse=True, beta_min=1e-6, gamma_init=.1),
+            ct(M, M), GDN(M, inverse=True, beta_min=1e-6, gamma_init=.1),
+            ct(M, M), GDN(M, inverse=True, beta_min=1e-6, gamma_init=.1),
+            ct(M, 3),
+        )
+
+
+class Decoder3x3(_Stack):
+    def __init__(self, latent_channels=192):
+        super().__init__()
+        M = latent_channels
+        self.net = nn.Sequential(
+            ResidualBlock(M, M), ResidualBlockUpsample(M, M, 2),
+            ResidualBlock(M, M), ResidualBlockUpsample(M, M, 2),
+            ResidualBlock(M, M), ResidualBlockUpsample(M, M, 2),
+            ResidualBlock(M, M), TransposedDeconv3x3(M, 3, 2),
+        )
+
+
+class HyperEncoder5x5(_Stack):
+    def __init__(self, latent_channels=192):
+        super().__init__()
+        M = latent_channels
+        self.net = nn.Sequential(
+            Conv2d(M, M, kernel_size=3, stride=1, padding=1), LeakyReLU(inplace=True),
+            Conv2d(M, M, kernel_size=5, stride=2, padding=2), LeakyReLU(inplace=True),
+            Conv2d(M, M, kernel_size=5, stride=2, padding=2),
+        )
+
+
+class HyperEncoder3x3(_Stack):
+    def __init__(self, latent_channels=192):
+        super().__init__()
+        M = latent_channels
+        self.net = nn.Sequential(
+            Conv2d(M, M, kernel_size=3, stride=1, padding=1), LeakyReLU(inplace=True),
+            Conv2d(M, M, kernel_size=3, stride=1, padding=1), LeakyReLU(inplace=True),
+            Conv2d(M, M, kernel_size=3, stride=2, padding=1), LeakyReLU(inplace=True),
+            Conv2d(M, M, kernel_size=3, stride=1, padding=1), LeakyReLU(inplace=True),
+            Conv2d(M, M, kernel_size=3, stride=2, padding=1),
+        )
+
+
+class HyperDecoder5x5(_Stack):
+    def __init__(self, latent_channels=192):
+        super().__init__()
+        M = latent_channels
+        self.net = nn.Sequential(
+            ConvTranspose2d(M, M, kernel_size=5, stride=2, padding=2, output_padding=1), LeakyReLU(inplace=True),
+            ConvTranspose2d(M, int(1.5 * M), kernel_size=5, stride=2, padding=2, output_padding=1),
+            LeakyReLU(inplace=True),
+            Conv2d(int(1.5 * M), 2 * M, kernel_size=3, stride=1, padding=1),
+        )
+
+
+class HyperDecoder3x3(_Stack):
+    def __init__(self, latent_channels=192):
+        super().__init__()
+        M = latent_channels
+        self.net = nn.Sequential(
+            Conv2d(M, M, kernel_size=3, stride=1, padding=1), LeakyReLU(inplace=True),
+            TransposedDeconv3x3(M, M, 2), LeakyReLU(inplace=True),
+            Conv2d(M, int(1.5 * M), kernel_size=3, stride=1, padding=1), LeakyReLU(inplace=True),
+            TransposedDeconv3x3(int(1.5 * M), int(1.5 * M), 2), LeakyReLU(inplace=True),
+            Conv2d(int(1.5 * M), 2 * M, kernel_size=3, stride=1, padding=1),
+        )

@@ -1,0 +1,666 @@
+"""torch.autograd.Function wrappers over the C ABI of liblic_hip.so.
+
+PyTorch here is plumbing only: it owns device memory, streams and the autograd graph.  Every
+arithmetic step of the hot path runs in the hand-written gfx950 kernels behind `_lib`.
+Tensors cross this boundary as NCHW-*logical* torch tensors whose physical layout is NHWC
+(channels_last); `_nhwc()` is a zero-copy permute when that already holds.
+
+No CPU fallback: a non-CUDA tensor or a missing extension raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib as L
+
+PEDESTAL = float(2.0 ** -36)  # compressai reparam_offset ** 2
+LIKELIHOOD_BOUND = 1e-9
+
+# bench.py sets this to a list to collect (kernel, flops, activation_bytes, start_evt, end_evt) for
+# every MFMA launch; HIP events are recorded on the stream the kernels are launched on.
+PROFILE = None
+
+
+# ------------------------------------------------------------------------------------------
+# plumbing helpers
+# ------------------------------------------------------------------------------------------
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _require_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise L.LicError("neural_image_compression_amd runs on MI355X only: got a non-CUDA tensor "
+                             "(there is no CPU fallback; the CPU oracle lives in oracle/ for tests)")
+        if t is not None and t.dtype != torch.float32:
+            raise L.LicError(f"fp32 tensors expected, got {t.dtype}")
+
+
+def _nhwc(t: torch.Tensor) -> torch.Tensor:
+    """NCHW-logical -> [B,H,W,C] contiguous (no copy if the tensor is channels_last already)."""
+    return t.permute(0, 2, 3, 1).contiguous()
+
+
+def _nchw_view(t_nhwc: torch.Tensor) -> torch.Tensor:
+    return t_nhwc.permute(0, 3, 1, 2)
+
+
+def _permute3(src, dst, n, s, d):
+    L.check(L.load().lic_permute3(_ptr(src), _ptr(dst), n[0], n[1], n[2], s[0], s[1], s[2], d[0], d[1],
+                                  d[2], _stream()), "lic_permute3")
+
+
+def _pack_conv_weight(w: torch.Tensor, transposed_weight: bool, for_dgrad: bool) -> torch.Tensor:
+    """-> packed [taps][K][N] fp32.  `transposed_weight`: w is [Cin,Cout,kh,kw] (ConvTranspose2d).
+    Forward contracts over the layer's input channels, dgrad over its output channels."""
+    w = w.contiguous()
+    d0, d1, kh, kw = w.shape
+    taps = kh * kw
+    # element (a, b, tap) of w at a*d1*taps + b*taps + tap
+    if transposed_weight:
+        cin, cout = d0, d1
+        s_ci, s_co = d1 * taps, taps
+    else:
+        cout, cin = d0, d1
+        s_co, s_ci = d1 * taps, taps
+    if for_dgrad:
+        K, N, sK, sN = cout, cin, s_co, s_ci
+    else:
+        K, N, sK, sN = cin, cout, s_ci, s_co
+    out = torch.empty((taps, K, N), device=w.device, dtype=torch.float32)
+    _permute3(w, out, (taps, K, N), (1, sK, sN), (K * N, N, 1))
+    return out
+
+
+def _igemm(inp, w_packed, out, *, B, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, pad, transposed,
+           bias=None, prologue=0, epilogue=L.EPI_NONE, slope=0.01, tap_mask=0, out2=None, aux=None,
+           aux2=None, aux3=None, res=None, in_ld=None, out_ld=None):
+    d = L.IgemmDesc()
+    d.in_, d.w, d.bias, d.out, d.out2 = _ptr(inp), _ptr(w_packed), _ptr(bias), _ptr(out), _ptr(out2)
+    d.aux, d.aux2, d.aux3, d.res = _ptr(aux), _ptr(aux2), _ptr(aux3), _ptr(res)
+    d.in_ld = Cin if in_ld is None else in_ld
+    d.out_ld = Cout if out_ld is None else out_ld
+    d.out2_ld = d.aux_ld = d.aux2_ld = d.aux3_ld = d.res_ld = Cout
+    d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout = B, Hi, Wi, Cin, Ho, Wo, Cout
+    d.kh, d.kw, d.stride, d.pad = kh, kw, stride, pad
+    d.transposed, d.prologue, d.epilogue = int(transposed), prologue, epilogue
+    d.tap_mask, d.slope = tap_mask, slope
+    lib = L.load()
+    if PROFILE is None:
+        L.check(lib.lic_igemm(C.byref(d), _stream()), "lic_igemm")
+        return
+    bm, bn, macs = C.c_int32(0), C.c_int32(0), C.c_int64(0)
+    lib.lic_igemm_plan(C.byref(d), C.byref(bm), C.byref(bn), C.byref(macs))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    L.check(lib.lic_igemm(C.byref(d), _stream()), "lic_igemm")
+    e1.record()
+    act_bytes = 4 * (B * Hi * Wi * Cin + B * Ho * Wo * Cout)
+    PROFILE.append((f"igemm_kernel<{bm.value},{bn.value}>", 2 * macs.value, act_bytes, e0, e1))
+
+
+def _wgrad(p, g, dst, *, B, Hs, Ws, Cp, Hl, Wl, Cg, kh, kw, stride, pad, g_is_row, dst_sm, dst_sn,
+           dst_stap, sq_p=0, sq_g=0, scale=1.0):
+    d = L.WgradDesc()
+    d.p, d.g, d.dst = _ptr(p), _ptr(g), _ptr(dst)
+    d.p_ld, d.g_ld = Cp, Cg
+    d.dst_sm, d.dst_sn, d.dst_stap = dst_sm, dst_sn, dst_stap
+    d.B, d.Hs, d.Ws, d.Cp, d.Hl, d.Wl, d.Cg = B, Hs, Ws, Cp, Hl, Wl, Cg
+    d.kh, d.kw, d.stride, d.pad = kh, kw, stride, pad
+    d.g_is_row, d.sq_p, d.sq_g, d.scale = int(g_is_row), sq_p, sq_g, scale
+    lib = L.load()
+    nbytes = lib.lic_wgrad_workspace_bytes(C.byref(d))
+    ws = torch.empty((max(nbytes, 4) + 3) // 4, device=p.device, dtype=torch.float32)
+    if PROFILE is None:
+        L.check(lib.lic_wgrad(C.byref(d), _ptr(ws), nbytes, _stream()), "lic_wgrad")
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    L.check(lib.lic_wgrad(C.byref(d), _ptr(ws), nbytes, _stream()), "lic_wgrad")
+    e1.record()
+    flops = 2 * B * Hs * Ws * kh * kw * Cp * Cg
+    PROFILE.append(("wgrad_kernel<64,64>+reduce", flops, 4 * (B * Hs * Ws * Cp + B * Hl * Wl * Cg), e0, e1))
+
+
+def _colsum(t2d: torch.Tensor, P: int, Cc: int, scale: float = 1.0) -> torch.Tensor:
+    lib = L.load()
+    nbytes = lib.lic_colsum_workspace_bytes(P, Cc)
+    ws = torch.empty((nbytes + 3) // 4, device=t2d.device, dtype=torch.float32)
+    out = torch.empty((Cc,), device=t2d.device, dtype=torch.float32)
+    L.check(lib.lic_colsum(_ptr(t2d), Cc, P, Cc, scale, _ptr(out), _ptr(ws), nbytes, _stream()),
+            "lic_colsum")
+    return out
+
+
+def _leaky_bwd(y, dy, slope):
+    dx = torch.empty_like(y)
+    L.check(L.load().lic_leaky_bwd(_ptr(y), _ptr(dy), _ptr(dx), y.numel(), slope, _stream()),
+            "lic_leaky_bwd")
+    return dx
+
+
+def conv_out_size(H, W, k, stride, pad, transposed, out_pad=0):
+    if transposed:
+        return (H - 1) * stride - 2 * pad + k + out_pad, (W - 1) * stride - 2 * pad + k + out_pad
+    return (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+
+
+# ------------------------------------------------------------------------------------------
+# convolution / transposed convolution with fused bias (+ LeakyReLU)
+# ------------------------------------------------------------------------------------------
+class _ConvFn(torch.autograd.Function):
+    """nn.Conv2d / nn.ConvTranspose2d (+ optional fused LeakyReLU) for channel counts >= 4.
+    Reference call sites: Components.py:10-16,39-45,69-73,99-103; Layers.py:21,38-43,74-76,99-103;
+    ParametersModels.py:22-34; ContextModels.py:19-20."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, out_pad, transposed, leaky, slope, tap_mask, res):
+        _require_cuda(x, weight, bias, res)
+        xh = _nhwc(x)
+        B, Hi, Wi, Cin = xh.shape
+        kh, kw = weight.shape[2], weight.shape[3]
+        Cout = weight.shape[1] if transposed else weight.shape[0]
+        Ho, Wo = conv_out_size(Hi, Wi, kh, stride, pad, transposed, out_pad)
+        wp = _pack_conv_weight(weight, transposed, for_dgrad=False)
+        out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+        resh = None if res is None else _nhwc(res)
+        # leaky + residual: `out` keeps leaky(conv) for the backward mask, `out2` = out + res
+        out2 = torch.empty_like(out) if (leaky and res is not None) else None
+        _igemm(xh, wp, out, B=B, Hi=Hi, Wi=Wi, Cin=Cin, Ho=Ho, Wo=Wo, Cout=Cout, kh=kh, kw=kw,
+               stride=stride, pad=pad, transposed=transposed, bias=bias,
+               epilogue=L.EPI_LEAKY if leaky else L.EPI_NONE, slope=slope, tap_mask=tap_mask,
+               res=resh, out2=out2)
+        ctx.save_for_backward(xh, weight, out if leaky else None)
+        ctx.cfg = (stride, pad, transposed, leaky, slope, tap_mask, bias is not None, res is not None)
+        return _nchw_view(out2 if out2 is not None else out)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xh, weight, yh = ctx.saved_tensors
+        stride, pad, transposed, leaky, slope, tap_mask, has_bias, has_res = ctx.cfg
+        g = _nhwc(gy)
+        if leaky:
+            g = _leaky_bwd(yh, g, slope)
+        B, Hi, Wi, Cin = xh.shape
+        _, Ho, Wo, Cout = g.shape
+        kh, kw = weight.shape[2], weight.shape[3]
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wp = _pack_conv_weight(weight, transposed, for_dgrad=True)
+            dxh = torch.empty_like(xh)
+            # the data gradient of a conv is the transposed gather and vice versa
+            _igemm(g, wp, dxh, B=B, Hi=Ho, Wi=Wo, Cin=Cout, Ho=Hi, Wo=Wi, Cout=Cin, kh=kh, kw=kw,
+                   stride=stride, pad=pad, transposed=not transposed, tap_mask=tap_mask)
+            dx = _nchw_view(dxh)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+            taps = kh * kw
+            if transposed:  # weight [Cin,Cout,kh,kw]; small grid = input, gathered = grad
+                _wgrad(xh, g, dw, B=B, Hs=Hi, Ws=Wi, Cp=Cin, Hl=Ho, Wl=Wo, Cg=Cout, kh=kh, kw=kw,
+                       stride=stride, pad=pad, g_is_row=False, dst_sm=Cout * taps, dst_sn=taps, dst_stap=1)
+            else:  # weight [Cout,Cin,kh,kw]; small grid = output grad, gathered = input
+                _wgrad(g, xh, dw, B=B, Hs=Ho, Ws=Wo, Cp=Cout, Hl=Hi, Wl=Wi, Cg=Cin, kh=kh, kw=kw,
+                       stride=stride, pad=pad, g_is_row=True, dst_sm=taps, dst_sn=Cin * taps, dst_stap=1)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = _colsum(g, B * Ho * Wo, Cout)
+        return dx, dw, db, None, None, None, None, None, None, None, (gy if has_res else None)
+
+
+def conv2d(x, weight, bias, stride=1, padding=0, leaky=False, slope=0.01, tap_mask=0, residual=None):
+    return _ConvFn.apply(x, weight, bias, stride, padding, 0, False, leaky, slope, tap_mask, residual)
+
+
+def conv_transpose2d(x, weight, bias, stride=1, padding=0, output_padding=0, leaky=False, slope=0.01,
+                     residual=None):
+    return _ConvFn.apply(x, weight, bias, stride, padding, output_padding, True, leaky, slope, 0, residual)
+
+
+# ------------------------------------------------------------------------------------------
+# image-side layers (3 channels): patches <-> columns + one dense GEMM
+# ------------------------------------------------------------------------------------------
+def _kpad(kh, kw, c):
+    return (kh * kw * c + 3) // 4 * 4
+
+
+class _ImageConvFn(torch.autograd.Function):
+    """nn.Conv2d whose INPUT has few channels (the RGB stem: Components.py:10; Layers.py:38,43
+    inside Encoder3x3's first block).  im2col (HBM-bound) + MFMA GEMM with K = kh*kw*C."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, leaky, slope):
+        _require_cuda(x, weight, bias)
+        xh = _nhwc(x)
+        B, Hi, Wi, Cin = xh.shape
+        Cout, _, kh, kw = weight.shape
+        Ho, Wo = conv_out_size(Hi, Wi, kh, stride, pad, False)
+        Kp = _kpad(kh, kw, Cin)
+        P = B * Ho * Wo
+        lib = L.load()
+        col = torch.empty((P, Kp), device=x.device, dtype=torch.float32)
+        L.check(lib.lic_im2col(_ptr(xh), _ptr(col), B, Hi, Wi, Cin, Ho, Wo, kh, kw, stride, pad, Kp,
+                               _stream()), "lic_im2col")
+        taps = kh * kw
+        wp = torch.zeros((Kp, Cout), device=x.device, dtype=torch.float32)
+        # wp[tap*Cin + c][co] = w[co][c][tap]
+        _permute3(weight.contiguous(), wp, (taps, Cin, Cout), (1, taps, Cin * taps), (Cin * Cout, Cout, 1))
+        out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+        _igemm(col, wp, out, B=1, Hi=1, Wi=P, Cin=Kp, Ho=1, Wo=P, Cout=Cout, kh=1, kw=1, stride=1,
+               pad=0, transposed=False, bias=bias, epilogue=L.EPI_LEAKY if leaky else L.EPI_NONE,
+               slope=slope)
+        ctx.save_for_backward(col, weight, out if leaky else None)
+        ctx.cfg = (stride, pad, leaky, slope, (B, Hi, Wi, Cin), bias is not None)
+        return _nchw_view(out)
+
+    @staticmethod
+    def backward(ctx, gy):
+        col, weight, yh = ctx.saved_tensors
+        stride, pad, leaky, slope, (B, Hi, Wi, Cin), has_bias = ctx.cfg
+        g = _nhwc(gy)
+        if leaky:
+            g = _leaky_bwd(yh, g, slope)
+        _, Ho, Wo, Cout = g.shape
+        _, _, kh, kw = weight.shape
+        taps, Kp, P = kh * kw, col.shape[1], B * Ho * Wo
+        lib = L.load()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wpT = torch.zeros((Cout, Kp), device=g.device, dtype=torch.float32)
+            _permute3(weight.contiguous(), wpT, (Cout, Cin, taps), (Cin * taps, taps, 1), (Kp, 1, Cin))
+            dcol = torch.empty((P, Kp), device=g.device, dtype=torch.float32)
+            _igemm(g, wpT, dcol, B=1, Hi=1, Wi=P, Cin=Cout, Ho=1, Wo=P, Cout=Kp, kh=1, kw=1, stride=1,
+                   pad=0, transposed=False)
+            dxh = torch.empty((B, Hi, Wi, Cin), device=g.device, dtype=torch.float32)
+            L.check(lib.lic_col2im(_ptr(dcol), None, _ptr(dxh), B, Ho, Wo, Cin, Hi, Wi, kh, kw, stride,
+                                   pad, Kp, _stream()), "lic_col2im")
+            dx = _nchw_view(dxh)
+        if ctx.needs_input_grad[1]:
+            tmp = torch.empty((Kp, Cout), device=g.device, dtype=torch.float32)
+            _wgrad(col, g, tmp, B=1, Hs=1, Ws=P, Cp=Kp, Hl=1, Wl=P, Cg=Cout, kh=1, kw=1, stride=1, pad=0,
+                   g_is_row=False, dst_sm=Cout, dst_sn=1, dst_stap=0)
+            dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+            _permute3(tmp, dw, (taps, Cin, Cout), (Cin * Cout, Cout, 1), (1, taps, Cin * taps))
+        if has_bias and ctx.needs_input_grad[2]:
+            db = _colsum(g, P, Cout)
+        return dx, dw, db, None, None, None, None
+
+
+class _ImageConvTFn(torch.autograd.Function):
+    """nn.ConvTranspose2d whose OUTPUT has few channels (the RGB head: Components.py:45;
+    Components.py:60 via Layers.py:21).  Dense MFMA GEMM to per-tap columns + col2im gather."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, out_pad):
+        _require_cuda(x, weight, bias)
+        xh = _nhwc(x)
+        B, Hi, Wi, Cin = xh.shape
+        _, Cout, kh, kw = weight.shape
+        Ho, Wo = conv_out_size(Hi, Wi, kh, stride, pad, True, out_pad)
+        taps, Kp, P = kh * kw, _kpad(kh, kw, Cout), B * Hi * Wi
+        lib = L.load()
+        wp = torch.zeros((Cin, Kp), device=x.device, dtype=torch.float32)
+        # wp[ci][tap*Cout + co] = w[ci][co][tap]
+        _permute3(weight.contiguous(), wp, (Cin, Cout, taps), (Cout * taps, taps, 1), (Kp, 1, Cout))
+        col = torch.empty((P, Kp), device=x.device, dtype=torch.float32)
+        _igemm(xh, wp, col, B=1, Hi=1, Wi=P, Cin=Cin, Ho=1, Wo=P, Cout=Kp, kh=1, kw=1, stride=1, pad=0,
+               transposed=False)
+        out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+        L.check(lib.lic_col2im(_ptr(col), _ptr(bias), _ptr(out), B, Hi, Wi, Cout, Ho, Wo, kh, kw, stride,
+                               pad, Kp, _stream()), "lic_col2im")
+        ctx.save_for_backward(xh, weight)
+        ctx.cfg = (stride, pad, (Ho, Wo), bias is not None)
+        return _nchw_view(out)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xh, weight = ctx.saved_tensors
+        stride, pad, (Ho, Wo), has_bias = ctx.cfg
+        g = _nhwc(gy)
+        B, Hi, Wi, Cin = xh.shape
+        _, Cout, kh, kw = weight.shape
+        taps, Kp, P = kh * kw, _kpad(kh, kw, Cout), B * Hi * Wi
+        lib = L.load()
+        dcol = torch.empty((P, Kp), device=g.device, dtype=torch.float32)
+        L.check(lib.lic_im2col(_ptr(g), _ptr(dcol), B, Ho, Wo, Cout, Hi, Wi, kh, kw, stride, pad, Kp,
+                               _stream()), "lic_im2col")
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wpT = torch.zeros((Kp, Cin), device=g.device, dtype=torch.float32)
+            _permute3(weight.contiguous(), wpT, (taps, Cout, Cin), (1, taps, Cout * taps),
+                      (Cout * Cin, Cin, 1))
+            dxh = torch.empty_like(xh)
+            _igemm(dcol, wpT, dxh, B=1, Hi=1, Wi=P, Cin=Kp, Ho=1, Wo=P, Cout=Cin, kh=1, kw=1, stride=1,
+                   pad=0, transposed=False)
+            dx = _nchw_view(dxh)
+        if ctx.needs_input_grad[1]:
+            tmp = torch.empty((Cin, Kp), device=g.device, dtype=torch.float32)
+            _wgrad(xh, dcol, tmp, B=1, Hs=1, Ws=P, Cp=Cin, Hl=1, Wl=P, Cg=Kp, kh=1, kw=1, stride=1, pad=0,
+                   g_is_row=False, dst_sm=Kp, dst_sn=1, dst_stap=0)
+            dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+            _permute3(tmp, dw, (Cin, taps, Cout), (Kp, Cout, 1), (Cout * taps, 1, taps))
+        if has_bias and ctx.needs_input_grad[2]:
+            db = _colsum(g, B * Ho * Wo, Cout)
+        return dx, dw, db, None, None, None
+
+
+def image_conv2d(x, weight, bias, stride, padding, leaky=False, slope=0.01):
+    return _ImageConvFn.apply(x, weight, bias, stride, padding, leaky, slope)
+
+
+def image_conv_transpose2d(x, weight, bias, stride, padding, output_padding):
+    return _ImageConvTFn.apply(x, weight, bias, stride, padding, output_padding)
+
+
+# ------------------------------------------------------------------------------------------
+# standalone LeakyReLU (modules that are used outside the fused stacks)
+# ------------------------------------------------------------------------------------------
+class _LeakyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, slope):
+        _require_cuda(x)
+        xc = x.contiguous()
+        # y = leaky(x) via the select kernel: y = x > 0 ? x : slope * x
+        y = _leaky_bwd(xc, xc, slope)
+        ctx.save_for_backward(y)
+        ctx.slope = slope
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (y,) = ctx.saved_tensors
+        return _leaky_bwd(y, gy.contiguous(), ctx.slope), None
+
+
+def leaky_relu(x, slope=0.01):
+    return _LeakyFn.apply(x, slope)
+
+
+# ------------------------------------------------------------------------------------------
+# GDN / IGDN (third-party compressai definition)
+# ------------------------------------------------------------------------------------------
+class _GDNFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, beta, gamma, inverse, beta_bound, gamma_bound, pedestal, res):
+        _require_cuda(x, beta, gamma, res)
+        lib = L.load()
+        xh = _nhwc(x)
+        B, H, W, Cc = xh.shape
+        beta_c, gamma_c = beta.contiguous(), gamma.contiguous()
+        beta_e = torch.empty_like(beta_c)
+        gamma_e = torch.empty_like(gamma_c)
+        L.check(lib.lic_gdn_reparam(_ptr(beta_c), _ptr(beta_e), Cc, beta_bound, pedestal, _stream()),
+                "lic_gdn_reparam")
+        L.check(lib.lic_gdn_reparam(_ptr(gamma_c), _ptr(gamma_e), Cc * Cc, gamma_bound, pedestal,
+                                    _stream()), "lic_gdn_reparam")
+        gT = torch.empty_like(gamma_e)  # B operand [k=j][n=i] = gamma_e[i][j]
+        _permute3(gamma_e, gT, (1, Cc, Cc), (0, 1, Cc), (0, Cc, 1))
+        out = torch.empty_like(xh)
+        norm = torch.empty_like(xh)
+        resh = None if res is None else _nhwc(res)
+        P = B * H * W
+        _igemm(xh, gT, out, B=1, Hi=1, Wi=P, Cin=Cc, Ho=1, Wo=P, Cout=Cc, kh=1, kw=1, stride=1, pad=0,
+               transposed=False, bias=beta_e, prologue=1, epilogue=L.EPI_IGDN if inverse else L.EPI_GDN,
+               out2=norm, aux=xh, res=resh)
+        ctx.save_for_backward(xh, norm, gamma_e, beta_c, gamma_c)
+        ctx.cfg = (inverse, beta_bound, gamma_bound, res is not None)
+        return _nchw_view(out)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xh, norm, gamma_e, beta_c, gamma_c = ctx.saved_tensors
+        inverse, beta_bound, gamma_bound, has_res = ctx.cfg
+        lib = L.load()
+        g = _nhwc(gy)
+        B, H, W, Cc = xh.shape
+        P = B * H * W
+        t = torch.empty_like(xh)
+        L.check(lib.lic_gdn_dnorm(_ptr(g), _ptr(xh), _ptr(norm), _ptr(t), xh.numel(), int(inverse),
+                                  _stream()), "lic_gdn_dnorm")
+        dx = dbeta = dgamma = None
+        if ctx.needs_input_grad[0]:
+            dxh = torch.empty_like(xh)
+            _igemm(t, gamma_e, dxh, B=1, Hi=1, Wi=P, Cin=Cc, Ho=1, Wo=P, Cout=Cc, kh=1, kw=1, stride=1,
+                   pad=0, transposed=False, epilogue=L.EPI_IGDN_BWD if inverse else L.EPI_GDN_BWD,
+                   aux=g, aux2=xh, aux3=norm)
+            dx = _nchw_view(dxh)
+        if ctx.needs_input_grad[1]:
+            dbe = _colsum(t, P, Cc)
+            dbeta = torch.empty_like(beta_c)
+            L.check(lib.lic_gdn_reparam_bwd(_ptr(beta_c), _ptr(dbe), _ptr(dbeta), Cc, beta_bound,
+                                            _stream()), "lic_gdn_reparam_bwd")
+        if ctx.needs_input_grad[2]:
+            dge = torch.empty_like(gamma_e)
+            _wgrad(t, xh, dge, B=1, Hs=1, Ws=P, Cp=Cc, Hl=1, Wl=P, Cg=Cc, kh=1, kw=1, stride=1, pad=0,
+                   g_is_row=False, dst_sm=Cc, dst_sn=1, dst_stap=0, sq_g=1)
+            dgamma = torch.empty_like(gamma_c)
+            L.check(lib.lic_gdn_reparam_bwd(_ptr(gamma_c), _ptr(dge), _ptr(dgamma), Cc * Cc, gamma_bound,
+                                            _stream()), "lic_gdn_reparam_bwd")
+        dres = gy if has_res else None
+        return dx, dbeta, dgamma, None, None, None, None, dres
+
+
+def gdn(x, beta, gamma, inverse, beta_bound, gamma_bound, pedestal=PEDESTAL, residual=None):
+    return _GDNFn.apply(x, beta, gamma, bool(inverse), float(beta_bound), float(gamma_bound),
+                        float(pedestal), residual)
+
+
+# ------------------------------------------------------------------------------------------
+# quantisation surrogate (Models.py:55-64)
+# ------------------------------------------------------------------------------------------
+class _QuantizeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, v, u, training):
+        _require_cuda(v, u)
+        vh = _nhwc(v)
+        uh = None if u is None else _nhwc(u)
+        out = torch.empty_like(vh)
+        L.check(L.load().lic_quantize(_ptr(vh), _ptr(uh), _ptr(out), vh.numel(), int(training), _stream()),
+                "lic_quantize")
+        ctx.training = training
+        return _nchw_view(out)
+
+    @staticmethod
+    def backward(ctx, g):
+        # additive noise: identity; round(): zero gradient (as torch.round)
+        return (g if ctx.training else torch.zeros_like(g)), None, None
+
+
+def quantize(v, u=None, training=True):
+    return _QuantizeFn.apply(v, u, training)
+
+
+# ------------------------------------------------------------------------------------------
+# entropy-parameter activations + conditional likelihood
+# ------------------------------------------------------------------------------------------
+class _EntropyParamsActFn(torch.autograd.Function):
+    """softplus(.)+1e-6 on scales, softmax over K on weights (ParametersModels.py:43-64)."""
+
+    @staticmethod
+    def forward(ctx, raw, M, K):
+        _require_cuda(raw)
+        rh = _nhwc(raw)
+        B, H, W, CH = rh.shape
+        out = torch.empty_like(rh)
+        L.check(L.load().lic_entropy_params_fwd(_ptr(rh), _ptr(out), B * H * W, M, K, _stream()),
+                "lic_entropy_params_fwd")
+        ctx.save_for_backward(rh, out)
+        ctx.cfg = (M, K)
+        return _nchw_view(out)
+
+    @staticmethod
+    def backward(ctx, g):
+        rh, out = ctx.saved_tensors
+        M, K = ctx.cfg
+        gh = _nhwc(g)
+        B, H, W, CH = rh.shape
+        d = torch.empty_like(rh)
+        L.check(L.load().lic_entropy_params_bwd(_ptr(rh), _ptr(out), _ptr(gh), _ptr(d), B * H * W, M, K,
+                                                _stream()), "lic_entropy_params_bwd")
+        return _nchw_view(d), None, None
+
+
+def entropy_params_activation(raw, M, K):
+    return _EntropyParamsActFn.apply(raw, M, K)
+
+
+class _GmmLikelihoodFn(torch.autograd.Function):
+    """p = clamp_min(sum_k w_k [Phi((x+.5-mu_k)/s_k) - Phi((x-.5-mu_k)/s_k)], bound); logp = log p
+    (EntropyModels.py:29-31,188-233; Models.py:86-87).  params: [B, G*K*M, h, w]."""
+
+    @staticmethod
+    def forward(ctx, x, params, K, bound):
+        _require_cuda(x, params)
+        xh, ph = _nhwc(x), _nhwc(params)
+        B, H, W, M = xh.shape
+        p = torch.empty_like(xh)
+        logp = torch.empty_like(xh)
+        L.check(L.load().lic_gmm_likelihood_fwd(_ptr(xh), _ptr(ph), _ptr(p), _ptr(logp), B * H * W, M, K,
+                                                bound, _stream()), "lic_gmm_likelihood_fwd")
+        ctx.save_for_backward(xh, ph)
+        ctx.cfg = (K, bound)
+        return _nchw_view(p), _nchw_view(logp)
+
+    @staticmethod
+    def backward(ctx, gp, glogp):
+        xh, ph = ctx.saved_tensors
+        K, bound = ctx.cfg
+        B, H, W, M = xh.shape
+        gph = None if gp is None else _nhwc(gp)
+        glh = None if glogp is None else _nhwc(glogp)
+        dx = torch.empty_like(xh)
+        dpar = torch.empty_like(ph)
+        L.check(L.load().lic_gmm_likelihood_bwd(_ptr(xh), _ptr(ph), _ptr(gph), _ptr(glh), _ptr(dx),
+                                                _ptr(dpar), B * H * W, M, K, bound, _stream()),
+                "lic_gmm_likelihood_bwd")
+        return _nchw_view(dx), _nchw_view(dpar), None, None
+
+
+def gmm_likelihood(x, params, K, bound=LIKELIHOOD_BOUND):
+    return _GmmLikelihoodFn.apply(x, params, K, bound)
+
+
+# ------------------------------------------------------------------------------------------
+# factorised bottleneck
+# ------------------------------------------------------------------------------------------
+_FE_SIZES = [3, 9, 9, 3, 3, 3, 3, 1, 3, 3, 3]
+
+
+class _FactorizedFn(torch.autograd.Function):
+    """EntropyModels.py:49-151 (+ clamp :29-31, log Models.py:83-84)."""
+
+    @staticmethod
+    def forward(ctx, x, bound, *plist):
+        _require_cuda(x, *plist)
+        Cc = plist[0].shape[0]
+        packed = torch.cat([q.reshape(Cc, -1) for q in plist], dim=1).contiguous()  # [C,43] (plumbing)
+        if x.dim() == 4:
+            xh = _nhwc(x)
+        else:  # (B, C) or (B, C, N): bring channels last
+            xh = x.reshape(x.shape[0], Cc, -1, 1).permute(0, 2, 3, 1).contiguous()
+        P = xh.numel() // Cc
+        p = torch.empty_like(xh)
+        logp = torch.empty_like(xh)
+        L.check(L.load().lic_factorized_fwd(_ptr(xh), _ptr(packed), _ptr(p), _ptr(logp), P, Cc, bound,
+                                            _stream()), "lic_factorized_fwd")
+        ctx.save_for_backward(xh, packed)
+        ctx.cfg = (bound, tuple(x.shape), [tuple(q.shape) for q in plist])
+        if x.dim() == 4:
+            return _nchw_view(p), _nchw_view(logp)
+        back = lambda t: t.permute(0, 3, 1, 2).reshape(x.shape)
+        return back(p), back(logp)
+
+    @staticmethod
+    def backward(ctx, gp, glogp):
+        xh, packed = ctx.saved_tensors
+        bound, xshape, pshapes = ctx.cfg
+        Cc = packed.shape[0]
+        P = xh.numel() // Cc
+
+        def to_h(g):
+            if g is None:
+                return None
+            if len(xshape) == 4:
+                return _nhwc(g)
+            return g.reshape(xshape[0], Cc, -1, 1).permute(0, 2, 3, 1).contiguous()
+        gph, glh = to_h(gp), to_h(glogp)
+        dx = torch.empty_like(xh)
+        dpk = torch.empty_like(packed)
+        L.check(L.load().lic_factorized_bwd(_ptr(xh), _ptr(packed), _ptr(gph), _ptr(glh), _ptr(dx), _ptr(dpk),
+                                            P, Cc, bound, _stream()), "lic_factorized_bwd")
+        dxo = _nchw_view(dx) if len(xshape) == 4 else dx.permute(0, 3, 1, 2).reshape(xshape)
+        grads = [g.reshape(s) for g, s in zip(torch.split(dpk, _FE_SIZES, dim=1), pshapes)]
+        return (dxo, None, *grads)
+
+
+def factorized_likelihood(x, matrices, biases, factors, bound=LIKELIHOOD_BOUND):
+    return _FactorizedFn.apply(x, bound, *matrices, *biases, *factors)
+
+
+def factorized_channel_logits(matrices, biases, factors, ch: int, xs: torch.Tensor) -> torch.Tensor:
+    _require_cuda(xs)
+    Cc = matrices[0].shape[0]
+    with torch.no_grad():
+        packed = torch.cat([q.reshape(Cc, -1) for q in (*matrices, *biases, *factors)], dim=1).contiguous()
+        xs_c = xs.contiguous()
+        out = torch.empty_like(xs_c)
+        L.check(L.load().lic_factorized_channel_logits(_ptr(packed), int(ch), _ptr(xs_c), _ptr(out),
+                                                       xs_c.numel(), _stream()),
+                "lic_factorized_channel_logits")
+    return out
+
+
+# ------------------------------------------------------------------------------------------
+# rate-distortion loss
+# ------------------------------------------------------------------------------------------
+class _RdLossFn(torch.autograd.Function):
+    """RateDistortionLoss.py:5-49 as one fused reduction; returns the small result buffer."""
+
+    @staticmethod
+    def forward(ctx, logp_y, logp_z, x_hat, x, lambda_rd):
+        _require_cuda(logp_y, logp_z, x_hat, x)
+        ly, lz = _nhwc(logp_y), _nhwc(logp_z)
+        xh, xx = _nhwc(x_hat), _nhwc(x)
+        B = xx.shape[0]
+        lib = L.load()
+        out = torch.zeros((16 + 2 * B,), device=x.device, dtype=torch.float32)
+        nbytes = lib.lic_rd_loss_workspace_bytes(B)
+        ws = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
+        num_pixels = xx.shape[1] * xx.shape[2]
+        L.check(lib.lic_rd_loss_fwd(_ptr(ly), ly.numel() // B, _ptr(lz), lz.numel() // B, _ptr(xh), _ptr(xx),
+                                    xx.numel() // B, B, num_pixels, lambda_rd, _ptr(out), _ptr(ws), nbytes,
+                                    _stream()), "lic_rd_loss_fwd")
+        ctx.save_for_backward(xh, xx)
+        ctx.cfg = (tuple(ly.shape), tuple(lz.shape), lambda_rd, num_pixels)
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        xh, xx = ctx.saved_tensors
+        shy, shz, lam, num_pixels = ctx.cfg
+        B = xx.shape[0]
+        gl = gout[0:1].contiguous()  # only `loss` carries gradient
+        dly = torch.empty(shy, device=xx.device, dtype=torch.float32)
+        dlz = torch.empty(shz, device=xx.device, dtype=torch.float32)
+        dxh = torch.empty_like(xh)
+        L.check(L.load().lic_rd_loss_bwd(_ptr(xh), _ptr(xx), dly.numel() // B, dlz.numel() // B,
+                                         xx.numel() // B, B, num_pixels, lam, _ptr(gl), _ptr(dly), _ptr(dlz),
+                                         _ptr(dxh), _stream()), "lic_rd_loss_bwd")
+        return _nchw_view(dly), _nchw_view(dlz), _nchw_view(dxh), None, None
+
+
+def rd_loss_buffer(logp_y, logp_z, x_hat, x, lambda_rd):
+    return _RdLossFn.apply(logp_y, logp_z, x_hat, x, float(lambda_rd))
+
+
+def mask_weight_(weight: torch.Tensor, mask: torch.Tensor):
+    """weight.data *= mask, in place (ContextModels.py:19)."""
+    _require_cuda(weight, mask)
+    L.check(L.load().lic_mul_inplace(_ptr(weight.data), _ptr(mask), weight.numel(), _stream()),
+            "lic_mul_inplace")

@@ -1,0 +1,172 @@
+"""Layer classes with the reference's names, constructor signatures, parameter shapes and
+state-dict keys, executing on the gfx950 kernels (functional.py).
+
+Mirrors (reference paths): Layers.py:6-119 (SubpelConv3x3 is never instantiated there and is
+not provided), third-party compressai.layers.gdn.GDN as used at Components.py:11-44 and
+Layers.py:41,75 (definition: SURVEY.md Appendix B; parity unpinned).
+
+Conv2d / ConvTranspose2d subclass torch's modules only to inherit their parameter containers
+and default initialisation (so `torch.manual_seed(s); Model()` draws the same weights as the
+reference); forward never touches ATen's convolution.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+from torch import Tensor
+
+from . import functional as F_
+
+
+def _pair(v):
+    return v if isinstance(v, int) else v[0]
+
+
+class Conv2d(nn.Conv2d):
+    def forward(self, x: Tensor, leaky: bool = False, slope: float = 0.01, residual=None) -> Tensor:
+        if self.groups != 1 or _pair(self.dilation) != 1:
+            raise NotImplementedError("groups/dilation are not used by the reference models")
+        s, p = _pair(self.stride), _pair(self.padding)
+        if self.in_channels < 4:  # RGB stem: im2col + dense MFMA GEMM
+            y = F_.image_conv2d(x, self.weight, self.bias, s, p, leaky, slope)
+            return y if residual is None else y + residual
+        return F_.conv2d(x, self.weight, self.bias, s, p, leaky, slope, 0, residual)
+
+
+class ConvTranspose2d(nn.ConvTranspose2d):
+    def forward(self, x: Tensor, leaky: bool = False, slope: float = 0.01, residual=None) -> Tensor:
+        if self.groups != 1 or _pair(self.dilation) != 1:
+            raise NotImplementedError("groups/dilation are not used by the reference models")
+        s, p, op = _pair(self.stride), _pair(self.padding), _pair(self.output_padding)
+        if self.out_channels < 4:  # RGB head: dense MFMA GEMM + col2im
+            if leaky or residual is not None:
+                raise NotImplementedError
+            return F_.image_conv_transpose2d(x, self.weight, self.bias, s, p, op)
+        return F_.conv_transpose2d(x, self.weight, self.bias, s, p, op, leaky, slope, residual)
+
+
+class LeakyReLU(nn.Module):
+    """nn.LeakyReLU stand-in; inside the stacks it is fused into the preceding conv's epilogue."""
+
+    def __init__(self, negative_slope: float = 0.01, inplace: bool = False):
+        super().__init__()
+        self.negative_slope = float(negative_slope)
+        self.inplace = inplace
+
+    def forward(self, x: Tensor) -> Tensor:
+        return F_.leaky_relu(x, self.negative_slope)
+
+
+def run_fused(seq: nn.Sequential, x: Tensor) -> Tensor:
+    """Run an nn.Sequential of our layers, folding Conv -> LeakyReLU pairs into one kernel."""
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        nxt = mods[i + 1] if i + 1 < len(mods) else None
+        fusable = isinstance(m, Conv2d) or (isinstance(m, ConvTranspose2d) and m.out_channels >= 4) or \
+            (type(m).__name__ == "TransposedDeconv3x3" and m.deconv.out_channels >= 4)
+        if fusable and isinstance(nxt, LeakyReLU):
+            x = m(x, leaky=True, slope=nxt.negative_slope)
+            i += 2
+        else:
+            x = m(x)
+            i += 1
+    return x
+
+
+# ---- GDN (compressai definition) -------------------------------------------------------------
+class LowerBound(nn.Module):
+    def __init__(self, bound: float):
+        super().__init__()
+        self.register_buffer("bound", torch.Tensor([float(bound)]))
+
+
+class NonNegativeParametrizer(nn.Module):
+    def __init__(self, minimum: float = 0.0, reparam_offset: float = 2 ** -18):
+        super().__init__()
+        self.minimum = float(minimum)
+        self.reparam_offset = float(reparam_offset)
+        pedestal = self.reparam_offset ** 2
+        self.register_buffer("pedestal", torch.Tensor([pedestal]))
+        self.lower_bound = LowerBound((self.minimum + pedestal) ** 0.5)
+        self.bound_value = float((self.minimum + pedestal) ** 0.5)
+        self.pedestal_value = float(pedestal)
+
+    def init(self, x: Tensor) -> Tensor:
+        return torch.sqrt(torch.max(x + self.pedestal, self.pedestal))
+
+
+class GDN(nn.Module):
+    """norm_i = beta_i + sum_j gamma_ij x_j^2;  y = x * rsqrt(norm)  (inverse: x * sqrt(norm))."""
+
+    def __init__(self, in_channels: int, inverse: bool = False, beta_min: float = 1e-6,
+                 gamma_init: float = 0.1):
+        super().__init__()
+        self.inverse = bool(inverse)
+        self.beta_reparam = NonNegativeParametrizer(minimum=float(beta_min))
+        self.beta = nn.Parameter(self.beta_reparam.init(torch.ones(int(in_channels))))
+        self.gamma_reparam = NonNegativeParametrizer()
+        self.gamma = nn.Parameter(self.gamma_reparam.init(float(gamma_init) * torch.eye(int(in_channels))))
+
+    def forward(self, x: Tensor, residual=None) -> Tensor:
+        return F_.gdn(x, self.beta, self.gamma, self.inverse, self.beta_reparam.bound_value,
+                      self.gamma_reparam.bound_value, self.beta_reparam.pedestal_value, residual)
+
+
+# ---- residual blocks (Layers.py:18-119) --------------------------------------------------------
+class TransposedDeconv3x3(nn.Module):
+    def __init__(self, in_ch, out_ch, upsample=2):
+        super().__init__()
+        self.deconv = ConvTranspose2d(in_ch, out_ch, kernel_size=3, stride=upsample, padding=1,
+                                      output_padding=upsample - 1)
+
+    def forward(self, x, leaky=False, slope=0.01):
+        return self.deconv(x, leaky=leaky, slope=slope)
+
+
+class ResidualBlockWithStride(nn.Module):
+    def __init__(self, in_ch: int, out_ch: int, stride: int = 2):
+        super().__init__()
+        self.conv1 = Conv2d(in_ch, out_ch, kernel_size=3, stride=stride, padding=1)
+        self.leaky_relu = LeakyReLU(inplace=True)
+        self.conv2 = Conv2d(out_ch, out_ch, kernel_size=3, stride=1, padding=1)
+        self.gdn = GDN(out_ch, beta_min=1e-6, gamma_init=.1)
+        self.skip = Conv2d(in_ch, out_ch, kernel_size=1, stride=stride) if (stride != 1 or in_ch != out_ch) else None
+
+    def forward(self, x: Tensor) -> Tensor:
+        out = self.conv1(x, leaky=True, slope=self.leaky_relu.negative_slope)
+        out = self.conv2(out)
+        identity = x if self.skip is None else self.skip(x)
+        return self.gdn(out, residual=identity)  # out += identity fused into the GDN epilogue
+
+
+class ResidualBlockUpsample(nn.Module):
+    def __init__(self, in_ch: int, out_ch: int, upsample: int = 2):
+        super().__init__()
+        self.subpel_conv = TransposedDeconv3x3(in_ch, out_ch, upsample)
+        self.leaky_relu = LeakyReLU(inplace=True)
+        self.conv = Conv2d(out_ch, out_ch, kernel_size=3, stride=1, padding=1)
+        self.igdn = GDN(out_ch, inverse=True, beta_min=1e-6, gamma_init=.1)
+        self.upsample = TransposedDeconv3x3(in_ch, out_ch, upsample)
+
+    def forward(self, x: Tensor) -> Tensor:
+        out = self.subpel_conv(x, leaky=True, slope=self.leaky_relu.negative_slope)
+        out = self.conv(out)
+        identity = self.upsample(x)
+        return self.igdn(out, residual=identity)
+
+
+class ResidualBlock(nn.Module):
+    def __init__(self, in_ch: int, out_ch: int):
+        super().__init__()
+        self.conv1 = Conv2d(in_ch, out_ch, kernel_size=3, stride=1, padding=1)
+        self.leaky_relu = LeakyReLU(inplace=True)
+        self.conv2 = Conv2d(out_ch, out_ch, kernel_size=3, stride=1, padding=1)
+        self.skip = Conv2d(in_ch, out_ch, kernel_size=1, stride=1) if in_ch != out_ch else None
+
+    def forward(self, x: Tensor) -> Tensor:
+        s = self.leaky_relu.negative_slope
+        out = self.conv1(x, leaky=True, slope=s)
+        identity = x if self.skip is None else self.skip(x)
+        return self.conv2(out, leaky=True, slope=s, residual=identity)  # leaky(conv2) + identity

@@ -1,0 +1,83 @@
+"""Model classes with the reference's names and forward contract (reference: Models.py:10-205).
+`ScalableImageCoding` (Models.py:208-338) is out of scope: its forward raises upstream."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from . import functional as F_
+from .components import (Decoder3x3, Decoder5x5, Encoder3x3, Encoder5x5, HyperDecoder3x3, HyperDecoder5x5,
+                         HyperEncoder3x3, HyperEncoder5x5)
+from .entropy import (ContextModel, EntropyParameters, FactorizedEntropyBottleneck, GaussianConditional,
+                      GaussianMixtureConditional)
+
+
+class _HyperpriorContextModel(nn.Module):
+    _stacks = None  # (Encoder, Decoder, HyperEncoder, HyperDecoder)
+
+    def __init__(self, latent_channels: int = 192, K: int = 1):
+        super().__init__()
+        if not isinstance(latent_channels, int) or latent_channels < 1:
+            raise ValueError(f"latent_channels must be int >= 1, got {latent_channels}")
+        if not isinstance(K, int) or K < 1:
+            raise ValueError(f"K must be int >= 1, got {K}")
+        self.M = latent_channels
+        self.K = K
+        self.H = latent_channels
+        self.distribution = 'Mean-Scale Gaussian' if K == 1 else 'Mixture of Gaussians'
+        self.conditional = GaussianConditional() if K == 1 else GaussianMixtureConditional()
+        Enc, Dec, HEnc, HDec = self._stacks
+        self.encoder = Enc(latent_channels=self.M)
+        self.decoder = Dec(latent_channels=self.M)
+        self.hyper_encoder = HEnc(latent_channels=self.M)
+        self.hyper_decoder = HDec(latent_channels=self.M)
+        self.factorized_entropy_model = FactorizedEntropyBottleneck(self.M)
+        self.context_model = ContextModel(latent_channels=self.M)
+        self.entropy_parameters = EntropyParameters(latent_channels=self.M, hyper_latent_channels=self.H,
+                                                    K=self.K)
+
+    def forward(self, x: torch.Tensor, training: bool = True, noise=None):
+        """`noise` (test hook, not in the reference): (u_z, u_y) uniform [0,1) tensors used instead
+        of torch.rand_like, in the reference's draw order (z first, Models.py:57-58)."""
+        if x.shape[2] % 64 or x.shape[3] % 64:
+            raise RuntimeError("H and W must be multiples of 64 (phi/psi shapes must agree, Models.py:73)")
+        y = self.encoder(x)
+        z = self.hyper_encoder(y)
+        if training:
+            if noise is None:
+                uz = torch.rand_like(z)
+                uy = torch.rand_like(y)
+            else:
+                uz, uy = noise
+            z_in = F_.quantize(z, uz, True)
+            y_in = F_.quantize(y, uy, True)
+        else:
+            z_in = F_.quantize(z, None, False)
+            y_in = F_.quantize(y, None, False)
+        psi = self.hyper_decoder(z_in)
+        phi = self.context_model(y_in)
+        combined = torch.cat([phi, psi], dim=1)  # layout copy only (phi first)
+        act = self.entropy_parameters.packed(combined)
+        if self.K == 1:
+            mu, sigma = self.entropy_parameters.split(act)
+            params = {"mu": mu, "sigma": sigma}
+        else:
+            weights, mus, sigmas = self.entropy_parameters.split(act)
+            params = {"weights": weights, "mus": mus, "sigmas": sigmas}
+        p_z, logp_z = self.factorized_entropy_model.likelihood_and_log(z_in)
+        p_y, logp_y = self.conditional.packed_likelihood_and_log(y_in, act, self.K)
+        x_hat = self.decoder(y_in)
+        out = {'x_hat': x_hat, 'y': y, 'y_in': y_in, 'z': z, 'z_in': z_in, 'p_z': p_z, 'logp_z': logp_z,
+               'p_y': p_y, 'logp_y': logp_y, 'training': training}
+        out.update(params)
+        return out
+
+
+class JointAutoregressiveHierarchical(_HyperpriorContextModel):
+    """5x5 conv/GDN stacks (Models.py:10-106)."""
+    _stacks = (Encoder5x5, Decoder5x5, HyperEncoder5x5, HyperDecoder5x5)
+
+
+class HierarchicalMixtureResidual(_HyperpriorContextModel):
+    """3x3 residual stacks (Models.py:109-205)."""
+    _stacks = (Encoder3x3, Decoder3x3, HyperEncoder3x3, HyperDecoder3x3)
