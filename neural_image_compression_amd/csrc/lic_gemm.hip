@@ -37,7 +37,7 @@ struct IgemmParams {
 constexpr int IG_BK = 16;
 constexpr int IG_LDA = IG_BK + 4;
 
-template <int BM, int BN>
+template <int BM, int BN, bool VEC>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   constexpr int WM = BM / 2, WN = BN / 2;    // 2x2 waves
   constexpr int TM = WM / 32, TN = WN / 32;  // MFMA tiles per wave
@@ -107,14 +107,18 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     for (int b = 0; b < TN; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-  bool n_live[TN];
+  int n_live_cnt = 0;  // live 32-column tiles of this wave (wave-uniform)
 #pragma unroll
-  for (int b = 0; b < TN; ++b) n_live[b] = (n0 + wn0 + b * 32) < p.Cout;
+  for (int b = 0; b < TN; ++b) n_live_cnt += ((n0 + wn0 + b * 32) < p.Cout) ? 1 : 0;
 
   const int ntaps = p.ntaps[phase];
   const int nchunks = ntaps * p.cpt;
   f32x4 ra[APASS], rb[BPASS];
+  bool ra_ok[APASS], rb_ok[BPASS];
 
+  // Issue the global loads of one chunk.  On the vector path nothing here consumes a loaded
+  // value (out-of-range lanes load from a safe address and are zeroed when the registers are
+  // written to LDS), so the loads stay in flight under the MFMAs of the current chunk.
   auto load_chunk = [&](int tapi, int cb) {
     const int tap = p.taps[phase][tapi];
     const int r = tap / p.kw, s = tap - r * p.kw;
@@ -135,49 +139,60 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
       }
       ok = ok && ih < p.Hi && iw < p.Wi;
       const int ci = ci0 + a_c4;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (ok) {
-        const float* src = p.in + (long)(a_base[j] + ih * p.Wi + iw) * p.in_ld + ci;
-        if (p.vec) {
-          if (ci < p.Cin) v = *reinterpret_cast<const f32x4*>(src);
-        } else {
+      if (VEC) {
+        ok = ok && ci < p.Cin;
+        const long off = ok ? (long)(a_base[j] + ih * p.Wi + iw) * p.in_ld + ci : 0L;
+        ra[j] = *reinterpret_cast<const f32x4*>(p.in + off);
+        ra_ok[j] = ok;
+      } else {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+          const float* src = p.in + (long)(a_base[j] + ih * p.Wi + iw) * p.in_ld + ci;
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             if (ci + e < p.Cin) v[e] = src[e];
         }
+        ra[j] = v;
+        ra_ok[j] = true;
       }
-      if (p.prologue == 1) v = v * v;
-      ra[j] = v;
     }
 #pragma unroll
     for (int j = 0; j < BPASS; ++j) {
       const int k = ci0 + b_kr[j];
       const int n = n0 + b_c4[j];
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (k < p.Cin) {
-        const float* src = p.w + ((long)tap * p.Cin + k) * p.Cout + n;
-        if (p.vec) {
-          if (n < p.Cout) v = *reinterpret_cast<const f32x4*>(src);
-        } else {
+      if (VEC) {
+        const bool ok = k < p.Cin && n < p.Cout;
+        const long off = ok ? ((long)tap * p.Cin + k) * p.Cout + n : 0L;
+        rb[j] = *reinterpret_cast<const f32x4*>(p.w + off);
+        rb_ok[j] = ok;
+      } else {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (k < p.Cin) {
+          const float* src = p.w + ((long)tap * p.Cin + k) * p.Cout + n;
 #pragma unroll
           for (int e = 0; e < 4; ++e)
             if (n + e < p.Cout) v[e] = src[e];
         }
+        rb[j] = v;
+        rb_ok[j] = true;
       }
-      rb[j] = v;
     }
   };
 
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
   int tapi = 0, cb = 0;
   if (nchunks > 0) load_chunk(0, 0);
   for (int c = 0; c < nchunks; ++c) {
     if (c > 0) __syncthreads();
 #pragma unroll
-    for (int j = 0; j < APASS; ++j)
-      *reinterpret_cast<f32x4*>(&sA[((tid >> 2) + 64 * j) * IG_LDA + a_c4]) = ra[j];
+    for (int j = 0; j < APASS; ++j) {
+      f32x4 v = ra_ok[j] ? ra[j] : zero4;
+      if (p.prologue == 1) v = v * v;
+      *reinterpret_cast<f32x4*>(&sA[((tid >> 2) + 64 * j) * IG_LDA + a_c4]) = v;
+    }
 #pragma unroll
     for (int j = 0; j < BPASS; ++j)
-      *reinterpret_cast<f32x4*>(&sB[b_kr[j] * BN + b_c4[j]]) = rb[j];
+      *reinterpret_cast<f32x4*>(&sB[b_kr[j] * BN + b_c4[j]]) = rb_ok[j] ? rb[j] : zero4;
     __syncthreads();
     if (++cb == p.cpt) {
       cb = 0;
@@ -201,14 +216,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     for (int b = 0; b < TN; ++b)
 #pragma unroll
       for (int t = 0; t < 8; ++t) bf[b][t] = sB[(lh * 8 + t) * BN + wn0 + b * 32 + li];
+    if (n_live_cnt == TN) {
 #pragma unroll
-    for (int t = 0; t < 8; ++t)
+      for (int t = 0; t < 8; ++t)
 #pragma unroll
-      for (int a = 0; a < TM; ++a)
+        for (int a = 0; a < TM; ++a)
 #pragma unroll
-        for (int b = 0; b < TN; ++b)
-          if (n_live[b])
+          for (int b = 0; b < TN; ++b)
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][t], bf[b][t], acc[a][b], 0, 0, 0);
+    } else if (n_live_cnt > 0) {  // only the first 32-column tile of this wave is live
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int a = 0; a < TM; ++a)
+          acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][t], bf[0][t], acc[a][0], 0, 0, 0);
+    }
   }
 
   // ---- epilogue -------------------------------------------------------------------------------
@@ -345,9 +367,10 @@ static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& 
   const int pad128 = ((d->Cout + 127) / 128) * 128;
   const int eff64 = ((d->Cout + 31) / 32) * 32;
   BN = (pad128 <= eff64 && d->Cout > 64) ? 128 : 64;
+  if (!p.vec) BN = 64;
   p.NT = (d->Cout + BN - 1) / BN;
   const long wg128 = ((maxP + 127) / 128) * p.NT * p.nphase;
-  BM = (wg128 >= 768) ? 128 : 64;
+  BM = (wg128 >= 768 && p.vec) ? 128 : 64;
   p.MT = (int)((maxP + BM - 1) / BM);
   nwg = (long)p.MT * p.NT * p.nphase;
   if (nwg > 0x7FFFFFFFL) return LIC_ERR_UNSUPPORTED;
@@ -377,14 +400,16 @@ LIC_EXPORT int lic_igemm(const lic_igemm_desc* d, lic_stream_t stream) {
   if (rc == 1) return LIC_OK;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)nwg), block(256);
-  if (BM == 128 && BN == 128)
-    hipLaunchKernelGGL((igemm_kernel<128, 128>), grid, block, 0, s, p);
+  if (!p.vec)  // odd channel counts / unaligned views: scalar-load variant, one tile shape
+    hipLaunchKernelGGL((igemm_kernel<64, 64, false>), grid, block, 0, s, p);
+  else if (BM == 128 && BN == 128)
+    hipLaunchKernelGGL((igemm_kernel<128, 128, true>), grid, block, 0, s, p);
   else if (BM == 128 && BN == 64)
-    hipLaunchKernelGGL((igemm_kernel<128, 64>), grid, block, 0, s, p);
+    hipLaunchKernelGGL((igemm_kernel<128, 64, true>), grid, block, 0, s, p);
   else if (BM == 64 && BN == 128)
-    hipLaunchKernelGGL((igemm_kernel<64, 128>), grid, block, 0, s, p);
+    hipLaunchKernelGGL((igemm_kernel<64, 128, true>), grid, block, 0, s, p);
   else
-    hipLaunchKernelGGL((igemm_kernel<64, 64>), grid, block, 0, s, p);
+    hipLaunchKernelGGL((igemm_kernel<64, 64, true>), grid, block, 0, s, p);
   return lic_check_launch();
 }
 
@@ -475,7 +500,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
       for (int e = 0; e < 4; ++e)
         if (ch + e < op.C) v[e] = src[e];
     }
-    if (op.sq) v = v * v;
     return v;
   };
 
@@ -493,10 +517,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     if (c > c_begin) __syncthreads();
 #pragma unroll
     for (int j = 0; j < APASS; ++j)
-      *reinterpret_cast<f32x4*>(&sA[a_kr[j] * TMt + a_c4[j]]) = ra[j];
+      *reinterpret_cast<f32x4*>(&sA[a_kr[j] * TMt + a_c4[j]]) = p.row.sq ? ra[j] * ra[j] : ra[j];
 #pragma unroll
     for (int j = 0; j < BPASS; ++j)
-      *reinterpret_cast<f32x4*>(&sB[b_kr[j] * TNt + b_c4[j]]) = rb[j];
+      *reinterpret_cast<f32x4*>(&sB[b_kr[j] * TNt + b_c4[j]]) = p.col.sq ? rb[j] * rb[j] : rb[j];
     __syncthreads();
     if (c + 1 < c_end) load_chunk(c + 1);
     float af[TM][8], bf[TN][8];
