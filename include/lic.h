@@ -58,7 +58,8 @@ enum lic_epilogue {
  *   transposed == 0:  out[b,oh,ow,:] = sum_{r,s} in[b, oh*stride-pad+r, ow*stride-pad+s, :] . W[r,s]
  *   transposed == 1:  out[b,oy,ox,:] = sum_{r,s : (oy+pad-r) % stride == 0 ...}
  *                                       in[b,(oy+pad-r)/stride,(ox+pad-s)/stride,:] . W[r,s]
- *   W is the packed weight [kh*kw][Cin][Cout] (see lic_permute3 for producing it).
+ *   W is the packed weight produced by lic_pack_weight: [kh*kw][ceil(Cin/16)][ceil32(Cout)][16]
+ *   (the MFMA B-operand order; lanes read it straight from L2 into registers).
  * Replaces: nn.Conv2d / nn.ConvTranspose2d forward and their input gradients
  *   (Components.py:10-16,39-45,69-73,99-103; Layers.py:21,38,40,43,74,76,99,101,103;
  *   ParametersModels.py:22-34; ContextModels.py:19-20 via tap_mask), the GDN/IGDN channel
@@ -88,6 +89,13 @@ typedef struct lic_igemm_desc {
 } lic_igemm_desc;
 
 int lic_igemm(const lic_igemm_desc* d, lic_stream_t stream);
+/* Weight packing for lic_igemm.  Logical element (tap, k, n) is read from
+ * src[tap*s_tap + k*s_k + n*s_n]; dst holds lic_packed_weight_floats(taps, K, N) floats
+ * (zero padded).  Any [Cout,Cin,kh,kw] / [Cin,Cout,kh,kw] weight, its transpose for the data
+ * gradient, or a dense [K][N] matrix is expressed through the three strides. */
+int64_t lic_packed_weight_floats(int32_t taps, int32_t K, int32_t N);
+int lic_pack_weight(const float* src, float* dst, int32_t taps, int32_t K, int32_t N, int64_t s_tap,
+                    int64_t s_k, int64_t s_n, lic_stream_t stream);
 /* which workgroup tile lic_igemm will launch for `d` (kernel name igemm_kernel<BM,BN>) and how
  * many multiply-adds it will issue on live taps: lets a profiler attribute time and FLOPs. */
 int lic_igemm_plan(const lic_igemm_desc* d, int32_t* BM, int32_t* BN, int64_t* live_macs);

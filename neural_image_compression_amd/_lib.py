@@ -44,6 +44,8 @@ class WgradDesc(C.Structure):
 SIGNATURES = {
     "lic_igemm": (C.c_int, [C.POINTER(IgemmDesc), _vp]),
     "lic_igemm_plan": (C.c_int, [C.POINTER(IgemmDesc), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i64)]),
+    "lic_packed_weight_floats": (_i64, [_i32, _i32, _i32]),
+    "lic_pack_weight": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _vp]),
     "lic_wgrad_workspace_bytes": (_sz, [C.POINTER(WgradDesc)]),
     "lic_wgrad": (C.c_int, [C.POINTER(WgradDesc), _vp, _sz, _vp]),
     "lic_colsum_workspace_bytes": (_sz, [_i64, _i32]),

@@ -5,6 +5,7 @@
 #include "lic_common.h"
 
 #define EW_BLOCK 256
+static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 // ---------------------------------------------------------------------------------------------
 // layout helpers
@@ -108,29 +109,51 @@ LIC_EXPORT int lic_col2im(const float* col, const float* bias, float* out, int32
 // ---------------------------------------------------------------------------------------------
 // column sums (bias gradients): two deterministic stages
 // ---------------------------------------------------------------------------------------------
-#define CS_MAXCHUNK 256
+#define CS_MAXCHUNK 512
+// block = 16 column groups (float4 = 64 columns) x 16 row lanes; grid (ceil(C/64), nchunk)
 __global__ __launch_bounds__(256) void colsum_stage1(const float* in, long ld, long P, int C, float* part,
-                                                     int nchunk) {
-  __shared__ float red[4][64];
-  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cx;
-  float acc = 0.0f;
-  if (c < C)
-    for (long pr = (long)blockIdx.y * 4 + ry; pr < P; pr += (long)nchunk * 4) acc += in[pr * ld + c];
-  red[ry][cx] = acc;
+                                                     int nchunk, int vec) {
+  __shared__ float red[16][64 + 4];
+  const int cg = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + cg * 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    if (vec) {
+      for (long pr = (long)blockIdx.y * 16 + ry; pr < P; pr += (long)nchunk * 16)
+        acc += *reinterpret_cast<const f32x4*>(in + pr * ld + c);
+    } else {
+      for (long pr = (long)blockIdx.y * 16 + ry; pr < P; pr += (long)nchunk * 16)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (c + e < C) acc[e] += in[pr * ld + c + e];
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[ry][cg * 4 + e] = acc[e];
   __syncthreads();
-  if (ry == 0 && c < C) part[(long)blockIdx.y * C + c] = (red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx]);
+  if (threadIdx.x < 64) {
+    const int cc = blockIdx.x * 64 + threadIdx.x;
+    float s = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += red[r][threadIdx.x];
+    if (cc < C) part[(long)blockIdx.y * C + cc] = s;
+  }
 }
+// block = 64 columns x 4 chunk lanes
 __global__ __launch_bounds__(256) void colsum_stage2(const float* part, int C, int nchunk, float scale,
                                                      float* out) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  if (c >= C) return;
+  __shared__ double red[4][64];
+  const int cx = threadIdx.x & 63, ly = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
   double acc = 0.0;
-  for (int y = 0; y < nchunk; ++y) acc += (double)part[(long)y * C + c];
-  out[c] = (float)(acc * (double)scale);
+  if (c < C)
+    for (int y = ly; y < nchunk; y += 4) acc += (double)part[(long)y * C + c];
+  red[ly][cx] = acc;
+  __syncthreads();
+  if (ly == 0 && c < C) out[c] = (float)(((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx])) * (double)scale);
 }
 static int colsum_chunks(int64_t P) {
-  int64_t n = cdiv64(P, 4 * 16);
+  int64_t n = cdiv64(P, 16 * 8);
   if (n > CS_MAXCHUNK) n = CS_MAXCHUNK;
   if (n < 1) n = 1;
   return (int)n;
@@ -145,11 +168,12 @@ LIC_EXPORT int lic_colsum(const float* in, int64_t ld, int64_t P, int32_t C, flo
   const int nchunk = colsum_chunks(P);
   if (workspace_bytes < (size_t)nchunk * C * sizeof(float)) return LIC_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
+  const int vec = (C % 4 == 0) && (ld % 4 == 0) && al16(in);
   hipLaunchKernelGGL(colsum_stage1, dim3((C + 63) / 64, nchunk), dim3(256), 0, s, in, (long)ld, (long)P, C,
-                     (float*)workspace, nchunk);
+                     (float*)workspace, nchunk, vec);
   int rc = lic_check_launch();
   if (rc != LIC_OK) return rc;
-  hipLaunchKernelGGL(colsum_stage2, dim3((C + 255) / 256), dim3(256), 0, s, (const float*)workspace, C,
+  hipLaunchKernelGGL(colsum_stage2, dim3((C + 63) / 64), dim3(256), 0, s, (const float*)workspace, C,
                      nchunk, scale, out);
   return lic_check_launch();
 }
@@ -179,7 +203,6 @@ static int ew_launch_vec(long n, bool can_vec, lic_stream_t stream, F4 f4, F1 f1
   if (tail0 < n) return ew_launch(n - tail0, stream, [=] __device__(long i) { f1(tail0 + i); });
   return LIC_OK;
 }
-static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 LIC_EXPORT int lic_mul_inplace(float* w, const float* mask, int64_t n, lic_stream_t stream) {
   if (!w || !mask || n < 0) return LIC_ERR_INVALID;

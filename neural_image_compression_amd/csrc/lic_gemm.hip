@@ -8,8 +8,35 @@
 
 thread_local int g_lic_last_hip_error = 0;
 
+// division of 0 <= n < 2^31 by a launch-constant d via multiply-high (host precomputes m, s)
+struct FastDiv {
+  unsigned m, s;
+};
+static FastDiv make_fastdiv(unsigned d) {
+  FastDiv f;
+  if (d == 0) d = 1;
+  unsigned s = 0;
+  while ((1ull << s) < d) ++s;
+  f.s = s;
+  f.m = (unsigned)(((1ull << (31 + s)) + d - 1) / d);
+  return f;
+}
+__device__ __forceinline__ int fdiv(int n, FastDiv f) {
+  return (int)(((unsigned long long)(unsigned)n * f.m) >> (31 + f.s));
+}
+
 // ------------------------------------------------------------------------------------------------
-// igemm
+// igemm: rows = output pixels (gathered from the NHWC input), cols = output channels.
+//
+// Workgroup = 4 waves as 2(M) x 2(N); wave tile = (BM/2) x (32*TN) in 32x32 MFMA tiles.
+//  * A (activations): each 16-deep K chunk is gathered global -> registers -> LDS ([BM][16+4]
+//    floats, conflict-free ds_read_b128 fragments), double-buffered so one barrier per chunk
+//    suffices; the loads of chunk c+2 are issued before the MFMAs of chunk c.
+//  * B (weights): never touches LDS.  lic_pack_weight lays them out [tap][chunk][Npad][16] so
+//    that lane (col j, half h) of a wave reads its 8 K-values of a chunk as two 16-byte loads
+//    straight into the MFMA B-operand registers (L2-resident, zero-padded: no guards).
+// Per chunk a wave issues TM*TN*8 MFMAs (up to 48 = 3072 cycles) against ~10 memory
+// instructions, which keeps LDS (the limiter of the first version of this kernel) nearly idle.
 // ------------------------------------------------------------------------------------------------
 struct IgemmParams {
   const float* in;
@@ -25,29 +52,34 @@ struct IgemmParams {
   int B, Hi, Wi, Cin, Ho, Wo, Cout;
   int kw, stride, pad, transposed, prologue, epilogue;
   float slope;
-  int vec;     // float4 global loads legal
+  int vec;     // float4 global loads of A legal
   int cpt;     // 16-deep chunks per tap
+  int Npad;    // Cout rounded up to 32 (packed weight pitch)
   int nphase;  // 1, or stride^2 output phases of a transposed conv
   int MT, NT;  // tiles in M (max over phases) and N
   int ntaps[4];
   int Hq[4], Wq[4];
+  FastDiv dHW[4], dW[4];  // divide by Hq*Wq and by Wq
   unsigned char taps[4][28];
 };
 
 constexpr int IG_BK = 16;
 constexpr int IG_LDA = IG_BK + 4;
 
-template <int BM, int BN, bool VEC>
+template <int BM, int TN, bool VEC>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
-  constexpr int WM = BM / 2, WN = BN / 2;    // 2x2 waves
-  constexpr int TM = WM / 32, TN = WN / 32;  // MFMA tiles per wave
-  constexpr int APASS = BM / 64;             // float4 A loads per thread per chunk
-  constexpr int BPASS = BN / 64;             // float4 B loads per thread per chunk
-  __shared__ __attribute__((aligned(16))) float sA[BM * IG_LDA];
-  __shared__ __attribute__((aligned(16))) float sB[IG_BK * BN];
+  constexpr int BN = 64 * TN;
+  constexpr int WM = BM / 2, WN = BN / 2;  // 2x2 waves
+  constexpr int TM = WM / 32;              // MFMA tiles per wave in M
+  constexpr int APASS = BM / 64;           // float4 A loads per thread per chunk
+  __shared__ __attribute__((aligned(16))) float sA[2][BM * IG_LDA];
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  // readfirstlane makes the wave index provably uniform: everything derived from it lives in
+  // SGPRs and branches on it are scalar (otherwise hipcc wraps each MFMA group in exec-mask
+  // branches and drains vmcnt to 0 around them)
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
   const int li = lane & 31, lh = lane >> 5;
 
@@ -58,9 +90,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
+  // phases interleave under one M tile index so that every XCD's contiguous id range holds all
+  // phases (their K lengths differ up to 2.25x: 9/6/6/4 taps for 5x5 stride 2)
   const int nt = wg % p.NT;
-  const int mt = (wg / p.NT) % p.MT;
-  const int phase = wg / (p.NT * p.MT);
+  const int phase = (wg / p.NT) % p.nphase;
+  const int mt = wg / (p.NT * p.nphase);
   const int Hq = p.Hq[phase], Wq = p.Wq[phase];
   const int P = p.B * Hq * Wq;
   const int m0 = mt * BM, n0 = nt * BN;
@@ -78,9 +112,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     const int prow = m0 + (tid >> 2) + 64 * j;
     a_ok[j] = prow < P;
     const int pr = a_ok[j] ? prow : 0;
-    const int b = pr / (Hq * Wq);
+    const int b = fdiv(pr, p.dHW[phase]);
     const int rem = pr - b * Hq * Wq;
-    const int i = rem / Wq, jj = rem - i * Wq;
+    const int i = fdiv(rem, p.dW[phase]), jj = rem - i * Wq;
     const int oy = i * sph + py, ox = jj * sph + px;
     a_base[j] = b * p.Hi * p.Wi;
     if (p.transposed) {
@@ -91,14 +125,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
       a_wx[j] = ox * p.stride - p.pad;
     }
   }
-  // B slots
-  int b_kr[BPASS], b_c4[BPASS];
-#pragma unroll
-  for (int j = 0; j < BPASS; ++j) {
-    const int idx = tid + 256 * j;
-    b_kr[j] = idx / (BN / 4);
-    b_c4[j] = (idx % (BN / 4)) * 4;
-  }
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -107,38 +133,33 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     for (int b = 0; b < TN; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-  int n_live_cnt = 0;  // live 32-column tiles of this wave (wave-uniform)
+  int n_live = 0;  // live 32-column tiles of this wave (wave-uniform)
 #pragma unroll
-  for (int b = 0; b < TN; ++b) n_live_cnt += ((n0 + wn0 + b * 32) < p.Cout) ? 1 : 0;
+  for (int b = 0; b < TN; ++b) n_live += ((n0 + wn0 + b * 32) < p.Npad) ? 1 : 0;
 
   const int ntaps = p.ntaps[phase];
   const int nchunks = ntaps * p.cpt;
-  f32x4 ra[APASS], rb[BPASS];
-  bool ra_ok[APASS], rb_ok[BPASS];
+  f32x4 ra[APASS];
+  bool ra_ok[APASS];
+  // this lane's B-operand address inside a (tap, chunk) panel: column n, K-half lh
+  const float* wlane = p.w + ((long)(n0 + wn0 + li) * IG_BK + lh * 8);
 
-  // Issue the global loads of one chunk.  On the vector path nothing here consumes a loaded
+  // Issue the global loads of one A chunk.  On the vector path nothing here consumes a loaded
   // value (out-of-range lanes load from a safe address and are zeroed when the registers are
-  // written to LDS), so the loads stay in flight under the MFMAs of the current chunk.
-  auto load_chunk = [&](int tapi, int cb) {
-    const int tap = p.taps[phase][tapi];
+  // written to LDS), so the loads stay in flight under the MFMAs.
+  const int sgn = p.transposed ? -1 : 1;
+  const int sh = (p.transposed && p.stride == 2) ? 1 : 0;  // stride is 1 or 2
+  const int last_tap = ntaps - 1, last_cb = p.cpt - 1;
+  auto load_a = [&](int tapi, int cb) {
+    const bool past = tapi > last_tap;  // cursor ran past the end: harmless duplicate load
+    const int tap = p.taps[phase][past ? last_tap : tapi];
     const int r = tap / p.kw, s = tap - r * p.kw;
-    const int ci0 = cb * IG_BK;
+    const int ci = (past ? last_cb : cb) * IG_BK + a_c4;
 #pragma unroll
     for (int j = 0; j < APASS; ++j) {
-      int ih, iw;
-      bool ok = a_ok[j];
-      if (p.transposed) {
-        const int nh = a_hy[j] - r, nw = a_wx[j] - s;
-        ok = ok && nh >= 0 && nw >= 0;
-        ih = (p.stride == 2) ? (nh >> 1) : nh / p.stride;
-        iw = (p.stride == 2) ? (nw >> 1) : nw / p.stride;
-      } else {
-        ih = a_hy[j] + r;
-        iw = a_wx[j] + s;
-        ok = ok && ih >= 0 && iw >= 0;
-      }
-      ok = ok && ih < p.Hi && iw < p.Wi;
-      const int ci = ci0 + a_c4;
+      const int nh = a_hy[j] + sgn * r, nw = a_wx[j] + sgn * s;
+      const int ih = nh >> sh, iw = nw >> sh;
+      bool ok = a_ok[j] && nh >= 0 && nw >= 0 && ih < p.Hi && iw < p.Wi;
       if (VEC) {
         ok = ok && ci < p.Cin;
         const long off = ok ? (long)(a_base[j] + ih * p.Wi + iw) * p.in_ld + ci : 0L;
@@ -156,80 +177,88 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         ra_ok[j] = true;
       }
     }
-#pragma unroll
-    for (int j = 0; j < BPASS; ++j) {
-      const int k = ci0 + b_kr[j];
-      const int n = n0 + b_c4[j];
-      if (VEC) {
-        const bool ok = k < p.Cin && n < p.Cout;
-        const long off = ok ? ((long)tap * p.Cin + k) * p.Cout + n : 0L;
-        rb[j] = *reinterpret_cast<const f32x4*>(p.w + off);
-        rb_ok[j] = ok;
-      } else {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (k < p.Cin) {
-          const float* src = p.w + ((long)tap * p.Cin + k) * p.Cout + n;
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (n + e < p.Cout) v[e] = src[e];
-        }
-        rb[j] = v;
-        rb_ok[j] = true;
-      }
-    }
   };
-
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  int tapi = 0, cb = 0;
-  if (nchunks > 0) load_chunk(0, 0);
-  for (int c = 0; c < nchunks; ++c) {
-    if (c > 0) __syncthreads();
+  const bool sq = p.prologue == 1;
+  auto store_a = [&](int buf) {
 #pragma unroll
     for (int j = 0; j < APASS; ++j) {
       f32x4 v = ra_ok[j] ? ra[j] : zero4;
-      if (p.prologue == 1) v = v * v;
-      *reinterpret_cast<f32x4*>(&sA[((tid >> 2) + 64 * j) * IG_LDA + a_c4]) = v;
+      v = sq ? v * v : v;
+      *reinterpret_cast<f32x4*>(&sA[buf][((tid >> 2) + 64 * j) * IG_LDA + a_c4]) = v;
     }
+  };
+  // dead 32-column tiles (beyond Npad) re-read the wave's last live tile instead of branching
+  int b_off[TN];
 #pragma unroll
-    for (int j = 0; j < BPASS; ++j)
-      *reinterpret_cast<f32x4*>(&sB[b_kr[j] * BN + b_c4[j]]) = rb_ok[j] ? rb[j] : zero4;
-    __syncthreads();
-    if (++cb == p.cpt) {
-      cb = 0;
-      ++tapi;
+  for (int b = 0; b < TN; ++b) b_off[b] = (b < n_live ? b : (n_live > 0 ? n_live - 1 : 0)) * 32 * IG_BK;
+  if (n_live == 0) wlane = p.w + lh * 8;
+  auto load_b = [&](f32x4 (&rb)[TN][2], int tapi, int cb) {
+    const bool past = tapi > last_tap;
+    const int tap = p.taps[phase][past ? last_tap : tapi];
+    const float* src = wlane + ((long)tap * p.cpt + (past ? last_cb : cb)) * p.Npad * IG_BK;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      rb[b][0] = *reinterpret_cast<const f32x4*>(src + b_off[b]);
+      rb[b][1] = *reinterpret_cast<const f32x4*>(src + b_off[b] + 4);
     }
-    if (c + 1 < nchunks) load_chunk(tapi, cb);
-
-    float af[TM][8], bf[TN][8];
+  };
+  auto compute = [&](int buf, const f32x4 (&rb)[TN][2]) {
+    f32x4 af[TM][2];
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
-      const float* src = &sA[(wm0 + a * 32 + li) * IG_LDA + lh * 8];
-      const f32x4 v0 = *reinterpret_cast<const f32x4*>(src);
-      const f32x4 v1 = *reinterpret_cast<const f32x4*>(src + 4);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        af[a][e] = v0[e];
-        af[a][4 + e] = v1[e];
-      }
+      const float* src = &sA[buf][(wm0 + a * 32 + li) * IG_LDA + lh * 8];
+      af[a][0] = *reinterpret_cast<const f32x4*>(src);
+      af[a][1] = *reinterpret_cast<const f32x4*>(src + 4);
     }
+    // one scalar branch per 32-column tile (n_live is wave-uniform); a single code path keeps
+    // every accumulator in one AGPR set
 #pragma unroll
     for (int b = 0; b < TN; ++b)
+      if (b < n_live) {
 #pragma unroll
-      for (int t = 0; t < 8; ++t) bf[b][t] = sB[(lh * 8 + t) * BN + wn0 + b * 32 + li];
-    if (n_live_cnt == TN) {
+        for (int t = 0; t < 8; ++t)
 #pragma unroll
-      for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-#pragma unroll
-          for (int b = 0; b < TN; ++b)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][t], bf[b][t], acc[a][b], 0, 0, 0);
-    } else if (n_live_cnt > 0) {  // only the first 32-column tile of this wave is live
-#pragma unroll
-      for (int t = 0; t < 8; ++t)
-#pragma unroll
-        for (int a = 0; a < TM; ++a)
-          acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][t], bf[0][t], acc[a][0], 0, 0, 0);
+          for (int a = 0; a < TM; ++a)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][t >> 2][t & 3], rb[b][t >> 2][t & 3],
+                                                              acc[a][b], 0, 0, 0);
+      }
+  };
+
+  // chunk cursor for the loads (runs ahead of the compute cursor)
+  int l_tap = 0, l_cb = 0;
+  auto advance = [&]() {
+    if (++l_cb == p.cpt) {
+      l_cb = 0;
+      ++l_tap;
+    }
+  };
+  f32x4 rb0[TN][2], rb1[TN][2];
+  if (nchunks > 0) {
+    load_a(0, 0);
+    load_b(rb0, 0, 0);
+    store_a(0);
+    __syncthreads();
+    advance();  // cursor -> chunk 1
+    load_a(l_tap, l_cb);
+    // Invariant at the top of an iteration on chunk c: sA[c&1] holds chunk c; `ra` holds chunk
+    // c+1 (in flight); rb(c&1) holds B of chunk c; the cursor points at chunk c+1.  Loads past
+    // the last chunk are clamped duplicates, so the body is free of conditionals.
+    for (int c = 0;; c += 2) {
+      load_b(rb1, l_tap, l_cb);
+      store_a(1);
+      advance();
+      load_a(l_tap, l_cb);
+      compute(0, rb0);
+      __syncthreads();
+      if (c + 1 >= nchunks) break;
+      load_b(rb0, l_tap, l_cb);
+      store_a(0);
+      advance();
+      load_a(l_tap, l_cb);
+      compute(1, rb1);
+      __syncthreads();
+      if (c + 2 >= nchunks) break;
     }
   }
 
@@ -244,9 +273,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
       if (prow >= P) continue;
       long opix;
       if (p.nphase > 1) {
-        const int b = prow / (Hq * Wq);
+        const int b = fdiv(prow, p.dHW[phase]);
         const int rem = prow - b * Hq * Wq;
-        const int i = rem / Wq, jj = rem - i * Wq;
+        const int i = fdiv(rem, p.dW[phase]), jj = rem - i * Wq;
         opix = ((long)b * p.Ho + i * sph + py) * p.Wo + jj * sph + px;
       } else {
         opix = prow;
@@ -281,14 +310,45 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 
 static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
+// ---- weight packing: dst[tap][chunk][n][16], zero padded to Npad = ceil32(N), K to 16 ---------
+__global__ __launch_bounds__(256) void pack_weight_kernel(const float* src, float* dst, int taps, int K,
+                                                          int N, int cpt, int Npad, long s_tap, long s_k,
+                                                          long s_n) {
+  const long total = (long)taps * cpt * Npad * IG_BK;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int kk = (int)(i & (IG_BK - 1));
+    long t = i >> 4;
+    const int n = (int)(t % Npad);
+    t /= Npad;
+    const int cb = (int)(t % cpt);
+    const int tap = (int)(t / cpt);
+    const int k = cb * IG_BK + kk;
+    dst[i] = (k < K && n < N) ? src[tap * s_tap + k * s_k + n * s_n] : 0.0f;
+  }
+}
+LIC_EXPORT int64_t lic_packed_weight_floats(int32_t taps, int32_t K, int32_t N) {
+  if (taps <= 0 || K <= 0 || N <= 0) return 0;
+  return (int64_t)taps * ((K + IG_BK - 1) / IG_BK) * (((N + 31) / 32) * 32) * IG_BK;
+}
+LIC_EXPORT int lic_pack_weight(const float* src, float* dst, int32_t taps, int32_t K, int32_t N,
+                               int64_t s_tap, int64_t s_k, int64_t s_n, lic_stream_t stream) {
+  if (!src || !dst || taps <= 0 || K <= 0 || N <= 0) return LIC_ERR_INVALID;
+  const int cpt = (K + IG_BK - 1) / IG_BK, Npad = ((N + 31) / 32) * 32;
+  const long total = (long)taps * cpt * Npad * IG_BK;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                     dst, taps, K, N, cpt, Npad, (long)s_tap, (long)s_k, (long)s_n);
+  return lic_check_launch();
+}
+
 // fills the kernel parameter block; returns LIC_OK, or 1 when there is nothing to launch
-static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& BN, long& nwg,
+static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& TN, long& nwg,
                          int64_t& live_macs) {
   if (!d || !d->in || !d->w || !d->out) return LIC_ERR_INVALID;
   if (d->B <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->Cin <= 0 || d->Ho <= 0 || d->Wo <= 0 ||
       d->Cout <= 0 || d->kh <= 0 || d->kw <= 0)
     return LIC_ERR_INVALID;
   if (d->kh * d->kw > 28 || d->stride < 1 || d->stride > 2) return LIC_ERR_UNSUPPORTED;
+  if (!aligned16(d->w)) return LIC_ERR_INVALID;
   const int epi = d->epilogue;
   if ((epi == LIC_EPI_MUL_LEAKY_MASK || epi == LIC_EPI_GDN || epi == LIC_EPI_IGDN) && !d->aux)
     return LIC_ERR_INVALID;
@@ -326,9 +386,9 @@ static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& 
   p.prologue = d->prologue;
   p.epilogue = epi;
   p.slope = d->slope;
-  p.vec = (d->Cin % 4 == 0) && (d->in_ld % 4 == 0) && (d->Cout % 4 == 0) && aligned16(d->in) &&
-          aligned16(d->w);
+  p.vec = (d->Cin % 4 == 0) && (d->in_ld % 4 == 0) && aligned16(d->in);
   p.cpt = (d->Cin + IG_BK - 1) / IG_BK;
+  p.Npad = ((d->Cout + 31) / 32) * 32;
   const uint32_t mask = d->tap_mask ? d->tap_mask : 0xFFFFFFFFu;
   p.nphase = (p.transposed && d->stride > 1) ? d->stride * d->stride : 1;
   long maxP = 0;
@@ -336,6 +396,7 @@ static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& 
   for (int ph = 0; ph < 4; ++ph) {
     p.ntaps[ph] = 0;
     p.Hq[ph] = p.Wq[ph] = 0;
+    p.dHW[ph] = p.dW[ph] = make_fastdiv(1);
   }
   for (int ph = 0; ph < p.nphase; ++ph) {
     const int py = (p.nphase > 1) ? ph / d->stride : 0, px = (p.nphase > 1) ? ph % d->stride : 0;
@@ -345,6 +406,8 @@ static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& 
     if (p.Hq[ph] < 0) p.Hq[ph] = 0;
     if (p.Wq[ph] < 0) p.Wq[ph] = 0;
     const long Pp = (long)d->B * p.Hq[ph] * p.Wq[ph];
+    p.dHW[ph] = make_fastdiv((unsigned)(p.Hq[ph] * p.Wq[ph]));
+    p.dW[ph] = make_fastdiv((unsigned)p.Wq[ph]);
     if (Pp > maxP) maxP = Pp;
     int n = 0;
     for (int r = 0; r < d->kh; ++r)
@@ -362,15 +425,30 @@ static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& 
   if (maxP <= 0) return 1;
   if (maxP > 0x7FFFFFFFL / 2) return LIC_ERR_UNSUPPORTED;
 
-  // tile selection: minimise padded N (a 64-wide tile whose second 32-column half is dead costs
-  // nothing: waves skip it); keep >= ~768 workgroups when the layer allows it
-  const int pad128 = ((d->Cout + 127) / 128) * 128;
-  const int eff64 = ((d->Cout + 31) / 32) * 32;
-  BN = (pad128 <= eff64 && d->Cout > 64) ? 128 : 64;
-  if (!p.vec) BN = 64;
-  p.NT = (d->Cout + BN - 1) / BN;
-  const long wg128 = ((maxP + 127) / 128) * p.NT * p.nphase;
-  BM = (wg128 >= 768 && p.vec) ? 128 : 64;
+  // Tile selection.  Dead 32-column tiles are skipped by the waves, so every BN wastes the same
+  // MFMA work; prefer the widest N tile (activations are gathered once per N tile) as long as
+  // the grid keeps >= 512 workgroups, else fall back towards small tiles for parallelism.
+  static const int cand[6][2] = {{128, 3}, {64, 3}, {128, 2}, {64, 2}, {128, 1}, {64, 1}};
+  int best = 5;
+  long best_wg = -1;
+  for (int c = 0; c < 6; ++c) {
+    const int bm = cand[c][0], tn = cand[c][1];
+    if (!p.vec && !(bm == 64 && tn == 1)) continue;  // scalar-A variant exists for one shape only
+    if (p.Npad < 64 * tn && tn > 1 && p.Npad <= 64 * (tn - 1)) continue;  // wider than the problem
+    const long wgs = ((maxP + bm - 1) / bm) * ((p.Npad + 64 * tn - 1) / (64 * tn)) * p.nphase;
+    if (wgs >= 512) {
+      best = c;
+      best_wg = wgs;
+      break;
+    }
+    if (wgs > best_wg) {
+      best = c;
+      best_wg = wgs;
+    }
+  }
+  BM = cand[best][0];
+  TN = cand[best][1];
+  p.NT = (p.Npad + 64 * TN - 1) / (64 * TN);
   p.MT = (int)((maxP + BM - 1) / BM);
   nwg = (long)p.MT * p.NT * p.nphase;
   if (nwg > 0x7FFFFFFFL) return LIC_ERR_UNSUPPORTED;
@@ -379,37 +457,41 @@ static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& 
 
 LIC_EXPORT int lic_igemm_plan(const lic_igemm_desc* d, int32_t* BM, int32_t* BN, int64_t* live_macs) {
   IgemmParams p;
-  int bm = 0, bn = 0;
+  int bm = 0, tn = 0;
   long nwg = 0;
   int64_t macs = 0;
-  const int rc = igemm_prepare(d, p, bm, bn, nwg, macs);
+  const int rc = igemm_prepare(d, p, bm, tn, nwg, macs);
   if (rc < 0) return rc;
   if (BM) *BM = bm;
-  if (BN) *BN = bn;
+  if (BN) *BN = 64 * tn;
   if (live_macs) *live_macs = macs;
   return LIC_OK;
 }
 
 LIC_EXPORT int lic_igemm(const lic_igemm_desc* d, lic_stream_t stream) {
   IgemmParams p;
-  int BM = 0, BN = 0;
+  int BM = 0, TN = 0;
   long nwg = 0;
   int64_t macs = 0;
-  const int rc = igemm_prepare(d, p, BM, BN, nwg, macs);
+  const int rc = igemm_prepare(d, p, BM, TN, nwg, macs);
   if (rc < 0) return rc;
   if (rc == 1) return LIC_OK;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)nwg), block(256);
   if (!p.vec)  // odd channel counts / unaligned views: scalar-load variant, one tile shape
-    hipLaunchKernelGGL((igemm_kernel<64, 64, false>), grid, block, 0, s, p);
-  else if (BM == 128 && BN == 128)
-    hipLaunchKernelGGL((igemm_kernel<128, 128, true>), grid, block, 0, s, p);
-  else if (BM == 128 && BN == 64)
-    hipLaunchKernelGGL((igemm_kernel<128, 64, true>), grid, block, 0, s, p);
-  else if (BM == 64 && BN == 128)
-    hipLaunchKernelGGL((igemm_kernel<64, 128, true>), grid, block, 0, s, p);
+    hipLaunchKernelGGL((igemm_kernel<64, 1, false>), grid, block, 0, s, p);
+  else if (BM == 128 && TN == 3)
+    hipLaunchKernelGGL((igemm_kernel<128, 3, true>), grid, block, 0, s, p);
+  else if (BM == 64 && TN == 3)
+    hipLaunchKernelGGL((igemm_kernel<64, 3, true>), grid, block, 0, s, p);
+  else if (BM == 128 && TN == 2)
+    hipLaunchKernelGGL((igemm_kernel<128, 2, true>), grid, block, 0, s, p);
+  else if (BM == 64 && TN == 2)
+    hipLaunchKernelGGL((igemm_kernel<64, 2, true>), grid, block, 0, s, p);
+  else if (BM == 128 && TN == 1)
+    hipLaunchKernelGGL((igemm_kernel<128, 1, true>), grid, block, 0, s, p);
   else
-    hipLaunchKernelGGL((igemm_kernel<64, 64, true>), grid, block, 0, s, p);
+    hipLaunchKernelGGL((igemm_kernel<64, 1, true>), grid, block, 0, s, p);
   return lic_check_launch();
 }
 
@@ -443,7 +525,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   constexpr int APASS = TMt / 64, BPASS = TNt / 64;
   __shared__ __attribute__((aligned(16))) float sA[WG_BK * TMt];
   __shared__ __attribute__((aligned(16))) float sB[WG_BK * TNt];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
   const int li = lane & 31, lh = lane >> 5;
   const int mt = blockIdx.x / p.NTt, nt = blockIdx.x % p.NTt;

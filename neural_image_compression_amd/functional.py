@@ -58,8 +58,24 @@ def _permute3(src, dst, n, s, d):
                                   d[2], _stream()), "lic_permute3")
 
 
+def _pack(src: torch.Tensor, taps: int, K: int, N: int, s_tap: int, s_k: int, s_n: int) -> torch.Tensor:
+    """Weights -> the MFMA B-operand layout of lic_igemm: [tap][K/16][ceil32(N)][16], zero padded.
+    Element (tap, k, n) is read from src[tap*s_tap + k*s_k + n*s_n]."""
+    lib = L.load()
+    out = torch.empty((lib.lic_packed_weight_floats(taps, K, N),), device=src.device, dtype=torch.float32)
+    L.check(lib.lic_pack_weight(_ptr(src), _ptr(out), taps, K, N, s_tap, s_k, s_n, _stream()),
+            "lic_pack_weight")
+    return out
+
+
+def _pack_dense(m: torch.Tensor) -> torch.Tensor:
+    """Row-major [K][N] matrix -> packed B operand."""
+    K, N = m.shape
+    return _pack(m, 1, K, N, 0, N, 1)
+
+
 def _pack_conv_weight(w: torch.Tensor, transposed_weight: bool, for_dgrad: bool) -> torch.Tensor:
-    """-> packed [taps][K][N] fp32.  `transposed_weight`: w is [Cin,Cout,kh,kw] (ConvTranspose2d).
+    """`transposed_weight`: w is [Cin,Cout,kh,kw] (ConvTranspose2d), else [Cout,Cin,kh,kw].
     Forward contracts over the layer's input channels, dgrad over its output channels."""
     w = w.contiguous()
     d0, d1, kh, kw = w.shape
@@ -72,12 +88,8 @@ def _pack_conv_weight(w: torch.Tensor, transposed_weight: bool, for_dgrad: bool)
         cout, cin = d0, d1
         s_co, s_ci = d1 * taps, taps
     if for_dgrad:
-        K, N, sK, sN = cout, cin, s_co, s_ci
-    else:
-        K, N, sK, sN = cin, cout, s_ci, s_co
-    out = torch.empty((taps, K, N), device=w.device, dtype=torch.float32)
-    _permute3(w, out, (taps, K, N), (1, sK, sN), (K * N, N, 1))
-    return out
+        return _pack(w, taps, cout, cin, 1, s_co, s_ci)
+    return _pack(w, taps, cin, cout, 1, s_ci, s_co)
 
 
 def _igemm(inp, w_packed, out, *, B, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, pad, transposed,
@@ -104,7 +116,8 @@ def _igemm(inp, w_packed, out, *, B, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, 
     L.check(lib.lic_igemm(C.byref(d), _stream()), "lic_igemm")
     e1.record()
     act_bytes = 4 * (B * Hi * Wi * Cin + B * Ho * Wo * Cout)
-    PROFILE.append((f"igemm_kernel<{bm.value},{bn.value}>", 2 * macs.value, act_bytes, e0, e1))
+    vec = "true" if (Cin % 4 == 0 and d.in_ld % 4 == 0) else "false"
+    PROFILE.append((f"igemm_kernel<{bm.value}, {bn.value // 64}, {vec}>", 2 * macs.value, act_bytes, e0, e1))
 
 
 def _wgrad(p, g, dst, *, B, Hs, Ws, Cp, Hl, Wl, Cg, kh, kw, stride, pad, g_is_row, dst_sm, dst_sn,
@@ -252,7 +265,7 @@ class _ImageConvFn(torch.autograd.Function):
         # wp[tap*Cin + c][co] = w[co][c][tap]
         _permute3(weight.contiguous(), wp, (taps, Cin, Cout), (1, taps, Cin * taps), (Cin * Cout, Cout, 1))
         out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
-        _igemm(col, wp, out, B=1, Hi=1, Wi=P, Cin=Kp, Ho=1, Wo=P, Cout=Cout, kh=1, kw=1, stride=1,
+        _igemm(col, _pack_dense(wp), out, B=1, Hi=1, Wi=P, Cin=Kp, Ho=1, Wo=P, Cout=Cout, kh=1, kw=1, stride=1,
                pad=0, transposed=False, bias=bias, epilogue=L.EPI_LEAKY if leaky else L.EPI_NONE,
                slope=slope)
         ctx.save_for_backward(col, weight, out if leaky else None)
@@ -275,7 +288,7 @@ class _ImageConvFn(torch.autograd.Function):
             wpT = torch.zeros((Cout, Kp), device=g.device, dtype=torch.float32)
             _permute3(weight.contiguous(), wpT, (Cout, Cin, taps), (Cin * taps, taps, 1), (Kp, 1, Cin))
             dcol = torch.empty((P, Kp), device=g.device, dtype=torch.float32)
-            _igemm(g, wpT, dcol, B=1, Hi=1, Wi=P, Cin=Cout, Ho=1, Wo=P, Cout=Kp, kh=1, kw=1, stride=1,
+            _igemm(g, _pack_dense(wpT), dcol, B=1, Hi=1, Wi=P, Cin=Cout, Ho=1, Wo=P, Cout=Kp, kh=1, kw=1, stride=1,
                    pad=0, transposed=False)
             dxh = torch.empty((B, Hi, Wi, Cin), device=g.device, dtype=torch.float32)
             L.check(lib.lic_col2im(_ptr(dcol), None, _ptr(dxh), B, Ho, Wo, Cin, Hi, Wi, kh, kw, stride,
@@ -309,7 +322,7 @@ class _ImageConvTFn(torch.autograd.Function):
         # wp[ci][tap*Cout + co] = w[ci][co][tap]
         _permute3(weight.contiguous(), wp, (Cin, Cout, taps), (Cout * taps, taps, 1), (Kp, 1, Cout))
         col = torch.empty((P, Kp), device=x.device, dtype=torch.float32)
-        _igemm(xh, wp, col, B=1, Hi=1, Wi=P, Cin=Cin, Ho=1, Wo=P, Cout=Kp, kh=1, kw=1, stride=1, pad=0,
+        _igemm(xh, _pack_dense(wp), col, B=1, Hi=1, Wi=P, Cin=Cin, Ho=1, Wo=P, Cout=Kp, kh=1, kw=1, stride=1, pad=0,
                transposed=False)
         out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
         L.check(lib.lic_col2im(_ptr(col), _ptr(bias), _ptr(out), B, Hi, Wi, Cout, Ho, Wo, kh, kw, stride,
@@ -336,7 +349,7 @@ class _ImageConvTFn(torch.autograd.Function):
             _permute3(weight.contiguous(), wpT, (taps, Cout, Cin), (1, taps, Cout * taps),
                       (Cout * Cin, Cin, 1))
             dxh = torch.empty_like(xh)
-            _igemm(dcol, wpT, dxh, B=1, Hi=1, Wi=P, Cin=Kp, Ho=1, Wo=P, Cout=Cin, kh=1, kw=1, stride=1,
+            _igemm(dcol, _pack_dense(wpT), dxh, B=1, Hi=1, Wi=P, Cin=Kp, Ho=1, Wo=P, Cout=Cin, kh=1, kw=1, stride=1,
                    pad=0, transposed=False)
             dx = _nchw_view(dxh)
         if ctx.needs_input_grad[1]:
@@ -399,8 +412,7 @@ class _GDNFn(torch.autograd.Function):
                 "lic_gdn_reparam")
         L.check(lib.lic_gdn_reparam(_ptr(gamma_c), _ptr(gamma_e), Cc * Cc, gamma_bound, pedestal,
                                     _stream()), "lic_gdn_reparam")
-        gT = torch.empty_like(gamma_e)  # B operand [k=j][n=i] = gamma_e[i][j]
-        _permute3(gamma_e, gT, (1, Cc, Cc), (0, 1, Cc), (0, Cc, 1))
+        gT = _pack(gamma_e, 1, Cc, Cc, 0, 1, Cc)  # B operand [k=j][n=i] = gamma_e[i][j]
         out = torch.empty_like(xh)
         norm = torch.empty_like(xh)
         resh = None if res is None else _nhwc(res)
@@ -426,7 +438,7 @@ class _GDNFn(torch.autograd.Function):
         dx = dbeta = dgamma = None
         if ctx.needs_input_grad[0]:
             dxh = torch.empty_like(xh)
-            _igemm(t, gamma_e, dxh, B=1, Hi=1, Wi=P, Cin=Cc, Ho=1, Wo=P, Cout=Cc, kh=1, kw=1, stride=1,
+            _igemm(t, _pack_dense(gamma_e), dxh, B=1, Hi=1, Wi=P, Cin=Cc, Ho=1, Wo=P, Cout=Cc, kh=1, kw=1, stride=1,
                    pad=0, transposed=False, epilogue=L.EPI_IGDN_BWD if inverse else L.EPI_GDN_BWD,
                    aux=g, aux2=xh, aux3=norm)
             dx = _nchw_view(dxh)
