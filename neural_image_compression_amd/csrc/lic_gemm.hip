@@ -93,8 +93,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   // phases interleave under one M tile index so that every XCD's contiguous id range holds all
   // phases (their K lengths differ up to 2.25x: 9/6/6/4 taps for 5x5 stride 2)
   const int nt = wg % p.NT;
-  const int phase = (wg / p.NT) % p.nphase;
-  const int mt = wg / (p.NT * p.nphase);
+  const int kq = wg / p.NT;
+  // Rotate the phase order from one M tile to the next.  Phase durations differ (9/6/6/4 taps)
+  // and the hardware deals consecutive workgroups round-robin over its shader engines / CUs:
+  // with a fixed period-4 order one engine would receive only 9-tap workgroups and pace all the
+  // others (measured: 1.2 instead of 1.9 resident waves per SIMD).
+  const int phase = (p.nphase == 4) ? ((kq + (kq >> 2) + (kq >> 4) + (kq >> 6) + (kq >> 8)) & 3) : 0;
+  const int mt = kq / p.nphase;
   const int Hq = p.Hq[phase], Wq = p.Wq[phase];
   const int P = p.B * Hq * Wq;
   const int m0 = mt * BM, n0 = nt * BN;

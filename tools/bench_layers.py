@@ -60,6 +60,14 @@ def main():
         if want(tag):
             m = GDN(M).to(dev)
             run(tag, lambda x: m(x), nhwc(B, M, hi, hi))
+    if want("probe"):
+        # short-K conv-gather (9 taps) vs transposed with the same per-workgroup work
+        w = torch.randn(M, M, 3, 3, device=dev, requires_grad=True)
+        b = torch.randn(M, device=dev, requires_grad=True)
+        run("probe conv3x3 s1 64x64", lambda x, w, b: F_.conv2d(x, w, b, 1, 1), nhwc(B, M, 64, 64), w, b)
+        run("probe convT3x3 s1 64x64", lambda x, w, b: F_.conv_transpose2d(x, w, b, 1, 1, 0), nhwc(B, M, 64, 64), w, b)
+        w1 = torch.randn(M, M, 1, 1, device=dev, requires_grad=True)
+        run("probe conv1x1 128x128", lambda x, w, b: F_.conv2d(x, w, b, 1, 0), nhwc(B, M, 128, 128), w1, b)
     if want("stem"):
         w = torch.randn(M, 3, 5, 5, device=dev, requires_grad=True)
         b = torch.randn(M, device=dev, requires_grad=True)
