@@ -125,6 +125,8 @@ typedef struct lic_wgrad_desc {
 
 size_t lic_wgrad_workspace_bytes(const lic_wgrad_desc* d);
 int lic_wgrad(const lic_wgrad_desc* d, void* workspace, size_t workspace_bytes, lic_stream_t stream);
+/* kernel variant wgrad_kernel<TM,TN,...> and split-K factor lic_wgrad will use (profiling aid) */
+int lic_wgrad_plan(const lic_wgrad_desc* d, int32_t* TM, int32_t* TN, int32_t* splitk);
 
 /* column sums over pixels: out[c] = scale * sum_p in[p*ld + c]  (bias gradients, GDN dbeta) */
 size_t lic_colsum_workspace_bytes(int64_t P, int32_t C);

@@ -48,6 +48,7 @@ SIGNATURES = {
     "lic_pack_weight": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _vp]),
     "lic_wgrad_workspace_bytes": (_sz, [C.POINTER(WgradDesc)]),
     "lic_wgrad": (C.c_int, [C.POINTER(WgradDesc), _vp, _sz, _vp]),
+    "lic_wgrad_plan": (C.c_int, [C.POINTER(WgradDesc), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "lic_colsum_workspace_bytes": (_sz, [_i64, _i32]),
     "lic_colsum": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _vp, _vp, _sz, _vp]),
     "lic_permute3": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _i64, _i64, _vp]),

@@ -501,7 +501,15 @@ LIC_EXPORT int lic_igemm(const lic_igemm_desc* d, lic_stream_t stream) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// wgrad: R[tap][m][n] = sum over small-grid pixels of row_operand[m] * col_operand[n]
+// wgrad: R[tap][m][n] = sum over small-grid pixels of row_operand[pix][m] * col_operand[pix][n]
+//
+// Both operands are activations (pixel-major, channels contiguous), so a 16-pixel K chunk of
+// each is staged through LDS as [16][channels] (16-byte global loads, conflict-free ds_read_b32
+// fragments).  Workgroup = 2x2 waves, wave tile = (32*TM) x (32*TN) accumulators; the big
+// variant (TM=2,TN=3: 128x192, 48 MFMAs per wave per chunk) keeps a whole 192-channel operand
+// in one tile.  LDS is double-buffered (one barrier per chunk) and the loads of chunk c+2 are in
+// flight under the MFMAs of chunk c.  K (pixels) is split across workgroups; partial slabs are
+// summed in a fixed order by wgrad_reduce_kernel (bitwise reproducible, no float atomics).
 // ------------------------------------------------------------------------------------------------
 struct WgOperand {
   const float* ptr;
@@ -509,7 +517,6 @@ struct WgOperand {
   int C;
   int gathered;  // sample the large grid at (hs*stride-pad+r, ws*stride-pad+s)
   int sq;
-  int vec;
 };
 struct WgradParams {
   WgOperand row, col;
@@ -519,41 +526,37 @@ struct WgradParams {
   int MTt, NTt;  // tiles
   int chunks_per_split, nchunks;
   long Ps;
+  FastDiv dHW, dW;  // divide by Hs*Ws and by Ws
 };
 
 constexpr int WG_BK = 16;
 
-template <int TMt, int TNt>
+template <int TM, int TN, bool VEC>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
-  constexpr int WM = TMt / 2, WN = TNt / 2;
-  constexpr int TM = WM / 32, TN = WN / 32;
-  constexpr int APASS = TMt / 64, BPASS = TNt / 64;
-  __shared__ __attribute__((aligned(16))) float sA[WG_BK * TMt];
-  __shared__ __attribute__((aligned(16))) float sB[WG_BK * TNt];
+  constexpr int BMt = 64 * TM, BNt = 64 * TN;
+  constexpr int WM = BMt / 2, WN = BNt / 2;
+  constexpr int APASS = (WG_BK * BMt / 4) / 256, BPASS = (WG_BK * BNt / 4) / 256;
+  __shared__ __attribute__((aligned(16))) float sA[2][WG_BK * BMt];
+  __shared__ __attribute__((aligned(16))) float sB[2][WG_BK * BNt];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
   const int li = lane & 31, lh = lane >> 5;
   const int mt = blockIdx.x / p.NTt, nt = blockIdx.x % p.NTt;
   const int tap = blockIdx.y, split = blockIdx.z;
-  const int m0 = mt * TMt, n0 = nt * TNt;
+  const int m0 = mt * BMt, n0 = nt * BNt;
   const int r = tap / p.kw, s = tap - r * p.kw;
   const int c_begin = split * p.chunks_per_split;
   const int c_end = min(p.nchunks, c_begin + p.chunks_per_split);
+  const int nloc = c_end - c_begin;
 
-  int a_kr[APASS], a_c4[APASS], b_kr[BPASS], b_c4[BPASS];
+  // live 32-wide sub-tiles of this wave (wave-uniform)
+  int m_live = 0, n_live = 0;
 #pragma unroll
-  for (int j = 0; j < APASS; ++j) {
-    const int idx = tid + 256 * j;
-    a_kr[j] = idx / (TMt / 4);
-    a_c4[j] = (idx % (TMt / 4)) * 4;
-  }
+  for (int a = 0; a < TM; ++a) m_live += ((m0 + wm0 + a * 32) < p.row.C) ? 1 : 0;
 #pragma unroll
-  for (int j = 0; j < BPASS; ++j) {
-    const int idx = tid + 256 * j;
-    b_kr[j] = idx / (TNt / 4);
-    b_c4[j] = (idx % (TNt / 4)) * 4;
-  }
+  for (int b = 0; b < TN; ++b) n_live += ((n0 + wn0 + b * 32) < p.col.C) ? 1 : 0;
+
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int a = 0; a < TM; ++a)
@@ -561,73 +564,114 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     for (int b = 0; b < TN; ++b)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.0f;
-  bool m_live[TM], n_live[TN];
-#pragma unroll
-  for (int a = 0; a < TM; ++a) m_live[a] = (m0 + wm0 + a * 32) < p.row.C;
-#pragma unroll
-  for (int b = 0; b < TN; ++b) n_live[b] = (n0 + wn0 + b * 32) < p.col.C;
 
-  auto load_op = [&](const WgOperand& op, long pk, int ch) -> f32x4 {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (pk >= p.Ps) return v;
-    long pix = pk;
-    if (op.gathered) {
-      const int hw = p.Hs * p.Ws;
-      const int b = (int)(pk / hw);
-      const int rem = (int)(pk - (long)b * hw);
-      const int hs = rem / p.Ws, ws = rem - hs * p.Ws;
-      const int hl = hs * p.stride - p.pad + r, wl = ws * p.stride - p.pad + s;
-      if (hl < 0 || wl < 0 || hl >= p.Hl || wl >= p.Wl) return v;
-      pix = ((long)b * p.Hl + hl) * p.Wl + wl;
-    }
-    const float* src = op.ptr + pix * op.ld + ch;
-    if (op.vec) {
-      if (ch < op.C) v = *reinterpret_cast<const f32x4*>(src);
-    } else {
+  // per-thread load slots: (pixel row kr within the chunk, channel c4)
+  int a_kr[APASS], a_c4[APASS], b_kr[BPASS], b_c4[BPASS];
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (ch + e < op.C) v[e] = src[e];
-    }
-    return v;
-  };
+  for (int j = 0; j < APASS; ++j) {
+    const int idx = tid + 256 * j;
+    a_kr[j] = idx / (BMt / 4);
+    a_c4[j] = (idx % (BMt / 4)) * 4;
+  }
+#pragma unroll
+  for (int j = 0; j < BPASS; ++j) {
+    const int idx = tid + 256 * j;
+    b_kr[j] = idx / (BNt / 4);
+    b_c4[j] = (idx % (BNt / 4)) * 4;
+  }
 
   f32x4 ra[APASS], rb[BPASS];
-  auto load_chunk = [&](int c) {
-    const long k0 = (long)c * WG_BK;
+  bool ra_ok[APASS], rb_ok[BPASS];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  auto load_op = [&](const WgOperand& op, long pk, int ch, f32x4& v, bool& okr) {
+    bool ok = pk < p.Ps;
+    long pix = ok ? pk : 0;
+    if (op.gathered) {
+      const int b = fdiv((int)pix, p.dHW);
+      const int rem = (int)pix - b * p.Hs * p.Ws;
+      const int hs = fdiv(rem, p.dW), ws = rem - hs * p.Ws;
+      const int hl = hs * p.stride - p.pad + r, wl = ws * p.stride - p.pad + s;
+      ok = ok && hl >= 0 && wl >= 0 && hl < p.Hl && wl < p.Wl;
+      pix = ((long)b * p.Hl + hl) * p.Wl + wl;
+    }
+    if (VEC) {
+      ok = ok && ch < op.C;
+      v = *reinterpret_cast<const f32x4*>(op.ptr + (ok ? pix * op.ld + ch : 0L));
+      okr = ok;
+    } else {
+      v = zero4;
+      if (ok) {
+        const float* src = op.ptr + pix * op.ld + ch;
 #pragma unroll
-    for (int j = 0; j < APASS; ++j) ra[j] = load_op(p.row, k0 + a_kr[j], m0 + a_c4[j]);
-#pragma unroll
-    for (int j = 0; j < BPASS; ++j) rb[j] = load_op(p.col, k0 + b_kr[j], n0 + b_c4[j]);
+        for (int e = 0; e < 4; ++e)
+          if (ch + e < op.C) v[e] = src[e];
+      }
+      okr = true;
+    }
   };
-
-  if (c_begin < c_end) load_chunk(c_begin);
-  for (int c = c_begin; c < c_end; ++c) {
-    if (c > c_begin) __syncthreads();
+  // chunk indices past the end are clamped to the last one (harmless duplicate loads)
+  auto load_chunk = [&](int c) {
+    const long k0 = (long)(c < c_end ? c : c_end - 1) * WG_BK;
 #pragma unroll
-    for (int j = 0; j < APASS; ++j)
-      *reinterpret_cast<f32x4*>(&sA[a_kr[j] * TMt + a_c4[j]]) = p.row.sq ? ra[j] * ra[j] : ra[j];
+    for (int j = 0; j < APASS; ++j) load_op(p.row, k0 + a_kr[j], m0 + a_c4[j], ra[j], ra_ok[j]);
 #pragma unroll
-    for (int j = 0; j < BPASS; ++j)
-      *reinterpret_cast<f32x4*>(&sB[b_kr[j] * TNt + b_c4[j]]) = p.col.sq ? rb[j] * rb[j] : rb[j];
-    __syncthreads();
-    if (c + 1 < c_end) load_chunk(c + 1);
+    for (int j = 0; j < BPASS; ++j) load_op(p.col, k0 + b_kr[j], n0 + b_c4[j], rb[j], rb_ok[j]);
+  };
+  const bool sqa = p.row.sq != 0, sqb = p.col.sq != 0;
+  auto store_chunk = [&](int buf) {
+#pragma unroll
+    for (int j = 0; j < APASS; ++j) {
+      f32x4 v = ra_ok[j] ? ra[j] : zero4;
+      v = sqa ? v * v : v;
+      *reinterpret_cast<f32x4*>(&sA[buf][a_kr[j] * BMt + a_c4[j]]) = v;
+    }
+#pragma unroll
+    for (int j = 0; j < BPASS; ++j) {
+      f32x4 v = rb_ok[j] ? rb[j] : zero4;
+      v = sqb ? v * v : v;
+      *reinterpret_cast<f32x4*>(&sB[buf][b_kr[j] * BNt + b_c4[j]]) = v;
+    }
+  };
+  auto compute = [&](int buf) {
     float af[TM][8], bf[TN][8];
 #pragma unroll
     for (int a = 0; a < TM; ++a)
 #pragma unroll
-      for (int t = 0; t < 8; ++t) af[a][t] = sA[(lh * 8 + t) * TMt + wm0 + a * 32 + li];
+      for (int t = 0; t < 8; ++t) af[a][t] = sA[buf][(lh * 8 + t) * BMt + wm0 + a * 32 + li];
 #pragma unroll
     for (int b = 0; b < TN; ++b)
 #pragma unroll
-      for (int t = 0; t < 8; ++t) bf[b][t] = sB[(lh * 8 + t) * TNt + wn0 + b * 32 + li];
+      for (int t = 0; t < 8; ++t) bf[b][t] = sB[buf][(lh * 8 + t) * BNt + wn0 + b * 32 + li];
 #pragma unroll
-    for (int t = 0; t < 8; ++t)
-#pragma unroll
-      for (int a = 0; a < TM; ++a)
+    for (int a = 0; a < TM; ++a)
+      if (a < m_live) {
 #pragma unroll
         for (int b = 0; b < TN; ++b)
-          if (m_live[a] && n_live[b])
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][t], bf[b][t], acc[a][b], 0, 0, 0);
+          if (b < n_live) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][t], bf[b][t], acc[a][b], 0, 0, 0);
+          }
+      }
+  };
+
+  if (nloc > 0) {
+    load_chunk(c_begin);
+    store_chunk(0);
+    __syncthreads();
+    load_chunk(c_begin + 1);
+    for (int c = 0;; c += 2) {
+      store_chunk(1);
+      load_chunk(c_begin + c + 2);
+      compute(0);
+      __syncthreads();
+      if (c + 1 >= nloc) break;
+      store_chunk(0);
+      load_chunk(c_begin + c + 3);
+      compute(1);
+      __syncthreads();
+      if (c + 2 >= nloc) break;
+    }
   }
   float* slab = p.slabs + ((long)split * p.ntaps + tap) * p.row.C * p.col.C;
 #pragma unroll
@@ -660,7 +704,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, f
 }
 
 struct WgPlan {
-  int TMt, TNt, MTt, NTt, ntaps, nchunks, splitk, cps;
+  int TM, TN, vec, MTt, NTt, ntaps, nchunks, splitk, cps;
   int Cm, Cn;
 };
 static int wg_plan(const lic_wgrad_desc* d, WgPlan* pl) {
@@ -670,14 +714,19 @@ static int wg_plan(const lic_wgrad_desc* d, WgPlan* pl) {
   pl->Cm = d->g_is_row ? d->Cg : d->Cp;
   pl->Cn = d->g_is_row ? d->Cp : d->Cg;
   pl->ntaps = d->kh * d->kw;
-  pl->TMt = 64;
-  pl->TNt = 64;
-  pl->MTt = (pl->Cm + 63) / 64;
-  pl->NTt = (pl->Cn + 63) / 64;
+  pl->vec = (d->Cp % 4 == 0) && (d->p_ld % 4 == 0) && aligned16(d->p) && (d->Cg % 4 == 0) &&
+            (d->g_ld % 4 == 0) && aligned16(d->g);
+  // tile: 128x192 when both operands are wide, else 64-granular
+  // 128-row tiles only when they come out full (a half-dead tile parks two of the four waves)
+  pl->TM = (pl->vec && pl->Cm > 64 && (pl->Cm % 128 == 0 || pl->Cm > 256)) ? 2 : 1;
+  pl->TN = (pl->vec && pl->Cn > 128) ? 3 : (pl->vec && pl->Cn > 64 ? 2 : 1);
+  if (pl->TM == 1 && pl->TN == 2) pl->TN = 1;  // instantiated shapes: (2,3) (2,2) (2,1) (1,3) (1,1)
+  pl->MTt = (pl->Cm + 64 * pl->TM - 1) / (64 * pl->TM);
+  pl->NTt = (pl->Cn + 64 * pl->TN - 1) / (64 * pl->TN);
   const long Ps = (long)d->B * d->Hs * d->Ws;
   pl->nchunks = (int)((Ps + WG_BK - 1) / WG_BK);
   const long base = (long)pl->MTt * pl->NTt * pl->ntaps;
-  long sk = (2048 + base - 1) / base;
+  long sk = (1024 + base - 1) / base;
   const long max_sk = (pl->nchunks + 15) / 16;  // at least 16 chunks (256 pixels) per split
   if (sk > max_sk) sk = max_sk;
   if (sk < 1) sk = 1;
@@ -702,20 +751,19 @@ LIC_EXPORT int lic_wgrad(const lic_wgrad_desc* d, void* workspace, size_t worksp
   if (d->stride < 1) return LIC_ERR_UNSUPPORTED;
   const size_t need = (size_t)pl.splitk * pl.ntaps * pl.Cm * pl.Cn * sizeof(float);
   if (workspace_bytes < need) return LIC_ERR_WORKSPACE;
+  if ((long)d->B * d->Hs * d->Ws > 0x7FFFFFFFL) return LIC_ERR_UNSUPPORTED;
   WgOperand P, G;
   P.ptr = d->p;
   P.ld = d->p_ld;
   P.C = d->Cp;
   P.gathered = 0;
   P.sq = d->sq_p;
-  P.vec = (d->Cp % 4 == 0) && (d->p_ld % 4 == 0) && aligned16(d->p);
   G.ptr = d->g;
   G.ld = d->g_ld;
   G.C = d->Cg;
   G.gathered = !(d->kh == 1 && d->kw == 1 && d->stride == 1 && d->pad == 0 && d->Hl == d->Hs &&
                  d->Wl == d->Ws);
   G.sq = d->sq_g;
-  G.vec = (d->Cg % 4 == 0) && (d->g_ld % 4 == 0) && aligned16(d->g);
   WgradParams p;
   p.row = d->g_is_row ? G : P;
   p.col = d->g_is_row ? P : G;
@@ -734,9 +782,22 @@ LIC_EXPORT int lic_wgrad(const lic_wgrad_desc* d, void* workspace, size_t worksp
   p.chunks_per_split = pl.cps;
   p.nchunks = pl.nchunks;
   p.Ps = (long)d->B * d->Hs * d->Ws;
+  p.dHW = make_fastdiv((unsigned)(d->Hs * d->Ws));
+  p.dW = make_fastdiv((unsigned)d->Ws);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(pl.MTt * pl.NTt, pl.ntaps, pl.splitk), block(256);
-  hipLaunchKernelGGL((wgrad_kernel<64, 64>), grid, block, 0, s, p);
+  if (!pl.vec)
+    hipLaunchKernelGGL((wgrad_kernel<1, 1, false>), grid, block, 0, s, p);
+  else if (pl.TM == 2 && pl.TN == 3)
+    hipLaunchKernelGGL((wgrad_kernel<2, 3, true>), grid, block, 0, s, p);
+  else if (pl.TM == 2 && pl.TN == 2)
+    hipLaunchKernelGGL((wgrad_kernel<2, 2, true>), grid, block, 0, s, p);
+  else if (pl.TM == 2 && pl.TN == 1)
+    hipLaunchKernelGGL((wgrad_kernel<2, 1, true>), grid, block, 0, s, p);
+  else if (pl.TM == 1 && pl.TN == 3)
+    hipLaunchKernelGGL((wgrad_kernel<1, 3, true>), grid, block, 0, s, p);
+  else
+    hipLaunchKernelGGL((wgrad_kernel<1, 1, true>), grid, block, 0, s, p);
   rc = lic_check_launch();
   if (rc != LIC_OK) return rc;
   const long total = (long)pl.ntaps * pl.Cm * pl.Cn;
@@ -744,6 +805,17 @@ LIC_EXPORT int lic_wgrad(const lic_wgrad_desc* d, void* workspace, size_t worksp
                      (const float*)workspace, d->dst, pl.splitk, pl.ntaps, pl.Cm, pl.Cn, (long)d->dst_sm,
                      (long)d->dst_sn, (long)d->dst_stap, d->scale);
   return lic_check_launch();
+}
+
+// kernel-variant name lic_wgrad will launch for `d` (profiling aid)
+LIC_EXPORT int lic_wgrad_plan(const lic_wgrad_desc* d, int32_t* TM, int32_t* TN, int32_t* splitk) {
+  WgPlan pl;
+  const int rc = wg_plan(d, &pl);
+  if (rc != LIC_OK) return rc;
+  if (TM) *TM = pl.vec ? pl.TM : 1;
+  if (TN) *TN = pl.vec ? pl.TN : 1;
+  if (splitk) *splitk = pl.splitk;
+  return LIC_OK;
 }
 
 LIC_EXPORT int lic_version(void) { return LIC_ABI_VERSION; }

@@ -140,7 +140,10 @@ def _wgrad(p, g, dst, *, B, Hs, Ws, Cp, Hl, Wl, Cg, kh, kw, stride, pad, g_is_ro
     L.check(lib.lic_wgrad(C.byref(d), _ptr(ws), nbytes, _stream()), "lic_wgrad")
     e1.record()
     flops = 2 * B * Hs * Ws * kh * kw * Cp * Cg
-    PROFILE.append(("wgrad_kernel<64,64>+reduce", flops, 4 * (B * Hs * Ws * Cp + B * Hl * Wl * Cg), e0, e1))
+    tm, tn, sk = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+    lib.lic_wgrad_plan(C.byref(d), C.byref(tm), C.byref(tn), C.byref(sk))
+    PROFILE.append((f"wgrad_kernel<{tm.value}, {tn.value}>+reduce", flops,
+                    4 * (B * Hs * Ws * Cp + B * Hl * Wl * Cg), e0, e1))
 
 
 def _colsum(t2d: torch.Tensor, P: int, Cc: int, scale: float = 1.0) -> torch.Tensor:
