@@ -53,6 +53,7 @@ struct IgemmParams {
   int kw, stride, pad, transposed, prologue, epilogue;
   float slope;
   int vec;     // float4 global loads of A legal
+  int vec_out; // 16-byte epilogue accesses legal (Cout, every ld and pointer 16-byte friendly)
   int cpt;     // 16-deep chunks per tap
   int Npad;    // Cout rounded up to 32 (packed weight pitch)
   int nphase;  // 1, or stride^2 output phases of a transposed conv
@@ -72,7 +73,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   constexpr int WM = BM / 2, WN = BN / 2;  // 2x2 waves
   constexpr int TM = WM / 32;              // MFMA tiles per wave in M
   constexpr int APASS = BM / 64;           // float4 A loads per thread per chunk
-  __shared__ __attribute__((aligned(16))) float sA[2][BM * IG_LDA];
+  // A double buffer; after the K loop the same memory stages 32x32 output tiles (one per wave)
+  constexpr int SA_FLOATS = (2 * BM * IG_LDA > 4 * 1024) ? 2 * BM * IG_LDA : 4 * 1024;
+  __shared__ __attribute__((aligned(16))) float smem[SA_FLOATS];
+  float(*sA)[BM * IG_LDA] = reinterpret_cast<float(*)[BM * IG_LDA]>(smem);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -269,48 +273,115 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 
   // ---- epilogue -------------------------------------------------------------------------------
   const int epi = p.epilogue;
+  if (p.vec_out) {
+    // Stage each 32x32 accumulator tile through LDS so that every lane owns 4 consecutive
+    // channels of a row: 16-byte loads/stores (1 KiB per wave instruction instead of 256 B; the
+    // GDN layers with their short K loops are bound by this epilogue's store issue).
+    float* stg = smem + wave * 1024;
+    const int c4 = (lane & 7) * 4, r8 = lane >> 3;
 #pragma unroll
-  for (int a = 0; a < TM; ++a)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-      const int prow = m0 + row;
-      if (prow >= P) continue;
-      long opix;
-      if (p.nphase > 1) {
-        const int b = fdiv(prow, p.dHW[phase]);
-        const int rem = prow - b * Hq * Wq;
-        const int i = fdiv(rem, p.dW[phase]), jj = rem - i * Wq;
-        opix = ((long)b * p.Ho + i * sph + py) * p.Wo + jj * sph + px;
-      } else {
-        opix = prow;
-      }
+    for (int a = 0; a < TM; ++a)
 #pragma unroll
       for (int b = 0; b < TN; ++b) {
-        const int col = n0 + wn0 + b * 32 + li;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = acc[a][b][r];
+        __syncthreads();
+        const int col = n0 + wn0 + b * 32 + c4;
         if (col >= p.Cout) continue;
-        float v = acc[a][b][r];
-        if (p.bias) v += p.bias[col];
-        if (epi == LIC_EPI_LEAKY) {
-          v = v > 0.0f ? v : v * p.slope;
-          if (p.res) p.out2[opix * p.out2_ld + col] = v + p.res[opix * p.res_ld + col];
-        } else {
-          if (epi == LIC_EPI_MUL_LEAKY_MASK) {
-            v = p.aux[opix * p.aux_ld + col] > 0.0f ? v : v * p.slope;
-          } else if (epi == LIC_EPI_GDN || epi == LIC_EPI_IGDN) {
-            if (p.out2) p.out2[opix * p.out2_ld + col] = v;
-            const float f = (epi == LIC_EPI_GDN) ? 1.0f / sqrtf(v) : sqrtf(v);
-            v = p.aux[opix * p.aux_ld + col] * f;
-          } else if (epi == LIC_EPI_GDN_BWD || epi == LIC_EPI_IGDN_BWD) {
-            const float n = p.aux3[opix * p.aux3_ld + col];
-            const float f = (epi == LIC_EPI_GDN_BWD) ? 1.0f / sqrtf(n) : sqrtf(n);
-            v = p.aux[opix * p.aux_ld + col] * f + 2.0f * p.aux2[opix * p.aux2_ld + col] * v;
+        f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bias4 = *reinterpret_cast<const f32x4*>(p.bias + col);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int rr = it * 8 + r8;
+          const int prow = m0 + wm0 + a * 32 + rr;
+          if (prow >= P) continue;
+          long opix;
+          if (p.nphase > 1) {
+            const int bb = fdiv(prow, p.dHW[phase]);
+            const int rem = prow - bb * Hq * Wq;
+            const int i = fdiv(rem, p.dW[phase]), jj = rem - i * Wq;
+            opix = ((long)bb * p.Ho + i * sph + py) * p.Wo + jj * sph + px;
+          } else {
+            opix = prow;
           }
-          if (p.res) v += p.res[opix * p.res_ld + col];
+          f32x4 v = *reinterpret_cast<const f32x4*>(&stg[rr * 32 + c4]) + bias4;
+          if (epi == LIC_EPI_LEAKY) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.0f ? v[e] : v[e] * p.slope;
+            if (p.res)
+              *reinterpret_cast<f32x4*>(p.out2 + opix * p.out2_ld + col) =
+                  v + *reinterpret_cast<const f32x4*>(p.res + opix * p.res_ld + col);
+          } else {
+            if (epi == LIC_EPI_MUL_LEAKY_MASK) {
+              const f32x4 m = *reinterpret_cast<const f32x4*>(p.aux + opix * p.aux_ld + col);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = m[e] > 0.0f ? v[e] : v[e] * p.slope;
+            } else if (epi == LIC_EPI_GDN || epi == LIC_EPI_IGDN) {
+              if (p.out2) *reinterpret_cast<f32x4*>(p.out2 + opix * p.out2_ld + col) = v;
+              const f32x4 x = *reinterpret_cast<const f32x4*>(p.aux + opix * p.aux_ld + col);
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                v[e] = x[e] * ((epi == LIC_EPI_GDN) ? 1.0f / sqrtf(v[e]) : sqrtf(v[e]));
+            } else if (epi == LIC_EPI_GDN_BWD || epi == LIC_EPI_IGDN_BWD) {
+              const f32x4 n = *reinterpret_cast<const f32x4*>(p.aux3 + opix * p.aux3_ld + col);
+              const f32x4 g = *reinterpret_cast<const f32x4*>(p.aux + opix * p.aux_ld + col);
+              const f32x4 x = *reinterpret_cast<const f32x4*>(p.aux2 + opix * p.aux2_ld + col);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float f = (epi == LIC_EPI_GDN_BWD) ? 1.0f / sqrtf(n[e]) : sqrtf(n[e]);
+                v[e] = g[e] * f + 2.0f * x[e] * v[e];
+              }
+            }
+            if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + opix * p.res_ld + col);
+          }
+          *reinterpret_cast<f32x4*>(p.out + opix * p.out_ld + col) = v;
         }
-        p.out[opix * p.out_ld + col] = v;
       }
-    }
+  } else {
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int prow = m0 + row;
+        if (prow >= P) continue;
+        long opix;
+        if (p.nphase > 1) {
+          const int b = fdiv(prow, p.dHW[phase]);
+          const int rem = prow - b * Hq * Wq;
+          const int i = fdiv(rem, p.dW[phase]), jj = rem - i * Wq;
+          opix = ((long)b * p.Ho + i * sph + py) * p.Wo + jj * sph + px;
+        } else {
+          opix = prow;
+        }
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          const int col = n0 + wn0 + b * 32 + li;
+          if (col >= p.Cout) continue;
+          float v = acc[a][b][r];
+          if (p.bias) v += p.bias[col];
+          if (epi == LIC_EPI_LEAKY) {
+            v = v > 0.0f ? v : v * p.slope;
+            if (p.res) p.out2[opix * p.out2_ld + col] = v + p.res[opix * p.res_ld + col];
+          } else {
+            if (epi == LIC_EPI_MUL_LEAKY_MASK) {
+              v = p.aux[opix * p.aux_ld + col] > 0.0f ? v : v * p.slope;
+            } else if (epi == LIC_EPI_GDN || epi == LIC_EPI_IGDN) {
+              if (p.out2) p.out2[opix * p.out2_ld + col] = v;
+              const float f = (epi == LIC_EPI_GDN) ? 1.0f / sqrtf(v) : sqrtf(v);
+              v = p.aux[opix * p.aux_ld + col] * f;
+            } else if (epi == LIC_EPI_GDN_BWD || epi == LIC_EPI_IGDN_BWD) {
+              const float n = p.aux3[opix * p.aux3_ld + col];
+              const float f = (epi == LIC_EPI_GDN_BWD) ? 1.0f / sqrtf(n) : sqrtf(n);
+              v = p.aux[opix * p.aux_ld + col] * f + 2.0f * p.aux2[opix * p.aux2_ld + col] * v;
+            }
+            if (p.res) v += p.res[opix * p.res_ld + col];
+          }
+          p.out[opix * p.out_ld + col] = v;
+        }
+      }
+  }
 }
 
 static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -394,6 +465,12 @@ static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& 
   p.vec = (d->Cin % 4 == 0) && (d->in_ld % 4 == 0) && aligned16(d->in);
   p.cpt = (d->Cin + IG_BK - 1) / IG_BK;
   p.Npad = ((d->Cout + 31) / 32) * 32;
+  {
+    auto okp = [](const void* q, int64_t ld) { return q == nullptr || (aligned16(q) && ld % 4 == 0); };
+    p.vec_out = (d->Cout % 4 == 0) && okp(d->out, d->out_ld) && okp(d->out2, d->out2_ld) &&
+                okp(d->aux, d->aux_ld) && okp(d->aux2, d->aux2_ld) && okp(d->aux3, d->aux3_ld) &&
+                okp(d->res, d->res_ld) && okp(d->bias, 4);
+  }
   const uint32_t mask = d->tap_mask ? d->tap_mask : 0xFFFFFFFFu;
   p.nphase = (p.transposed && d->stride > 1) ? d->stride * d->stride : 1;
   long maxP = 0;
