@@ -1,0 +1,1 @@
+from neural_image_compression_amd.models import HierarchicalMixtureResidual, JointAutoregressiveHierarchical  # noqa: F401

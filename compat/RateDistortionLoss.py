@@ -1,0 +1,1 @@
+from neural_image_compression_amd.loss import rd_loss  # noqa: F401

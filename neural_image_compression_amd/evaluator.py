@@ -1,0 +1,85 @@
+"""Evaluation-loop counterpart of the reference's CompressionEvaluator (Evaluator.py:17-92,
+235-242): per-batch bpp_total / bpp_y / bpp_z from rd_loss, MSE(255), PSNR(RGB) on
+x_hat.clamp(0,1), luma PSNR with BT.601 weights, and the result-file format.
+
+Differences, stated: MS-SSIM needs the third-party `pytorch_msssim` (absent offline; SURVEY.md
+8(f)) and is reported only when that package is importable.  The reference's aggregation reports
+`BPP` = mean(bpp_y) (Evaluator.py:81 uses bpp_y_values); this class reproduces that under 'BPP'
+for drop-in compatibility and adds the intended value as 'BPP(total)'.
+"""
+from __future__ import annotations
+
+import math
+import os
+
+import numpy as np
+import torch
+
+
+class CompressionEvaluator:
+    def __init__(self, model, dataloader, device, lambda_val, save_dir="./eval_results"):
+        self.model = model
+        self.dataloader = dataloader
+        self.device = device
+        self.lambda_val = lambda_val
+        os.makedirs(save_dir, exist_ok=True)
+        self.save_dir = save_dir
+        try:
+            from pytorch_msssim import ms_ssim  # noqa: WPS433
+            self._ms_ssim = ms_ssim
+        except Exception:
+            self._ms_ssim = None
+
+    @staticmethod
+    def rgb_to_luma(x):
+        R, G, B = x[:, 0], x[:, 1], x[:, 2]
+        return 0.299 * R + 0.587 * G + 0.114 * B
+
+    def compute_metrics(self, orig, recon):
+        mse_rgb = torch.mean((orig - recon) ** 2).item()
+        out = {"MSE(255)": mse_rgb * (255 ** 2),
+               "PSNR(RGB)": 10 * math.log10(1.0 / mse_rgb) if mse_rgb > 0 else float('inf')}
+        Y_orig = self.rgb_to_luma(orig).unsqueeze(1)
+        Y_recon = self.rgb_to_luma(recon).unsqueeze(1)
+        mse_y = torch.mean((Y_orig - Y_recon) ** 2).item()
+        if self._ms_ssim is not None:
+            out["MS-SSIM(RGB)"] = self._ms_ssim(recon, orig, data_range=1.0, size_average=True).item()
+        out["PSNR(Y)"] = 10 * math.log10(1.0 / mse_y) if mse_y > 0 else float('inf')
+        if self._ms_ssim is not None:
+            out["MS-SSIM(Y)"] = self._ms_ssim(Y_recon, Y_orig, data_range=1.0, size_average=True).item()
+        return out
+
+    def evaluate(self, rd_loss_fn):
+        self.model.eval()
+        total_metrics, bpp_values, bpp_y_values, bpp_z_values = [], [], [], []
+        imgs_list, recon_list = [], []
+        with torch.no_grad():
+            for imgs in self.dataloader:
+                imgs = imgs.to(self.device)
+                out = self.model(imgs, training=False)
+                results = rd_loss_fn(out, imgs, self.lambda_val)
+                bpp_values.append(results["bpp_total"])
+                bpp_y_values.append(results["bpp_y"])
+                bpp_z_values.append(results["bpp_z"])
+                total_metrics.append(self.compute_metrics(imgs, out["x_hat"].clamp(0, 1)))
+                imgs_list.append(imgs[0].cpu())
+                recon_list.append(out["x_hat"][0].cpu().clamp(0, 1))
+        avg_metrics = {k: float(np.mean([m[k] for m in total_metrics])) for k in total_metrics[0]}
+        avg_metrics['BPP'] = float(np.mean(bpp_y_values))  # as the reference computes it (Evaluator.py:81)
+        avg_metrics['BPP(y)'] = float(np.mean(bpp_y_values))
+        avg_metrics['BPP(z)'] = float(np.mean(bpp_z_values))
+        avg_metrics['BPP(total)'] = float(np.mean(bpp_values))
+        print("\n--- Evaluation Results ---")
+        for k, v in avg_metrics.items():
+            print(f"{k}: {v:.6f}")
+        return avg_metrics, imgs_list, recon_list
+
+    def save_results(self, metrics, nb_steps, caption=""):
+        path = os.path.join(self.save_dir, f"eval_results_{self.lambda_val}_lambda_" + caption + ".txt")
+        with open(path, "w") as f:
+            f.write(f"Lambda: {self.lambda_val}\n")
+            f.write(f"Trained for: {nb_steps} steps\n")
+            for k, v in metrics.items():
+                f.write(f"{k}: {v:.6f}\n")
+        print(f"Results saved to {path}")
+        return path

@@ -1,0 +1,158 @@
+"""Host-side mirror of the reference's module surface: constructors, state-dict layout, error
+behaviour, trainer bookkeeping.  CPU only."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import neural_image_compression_amd as nic
+from neural_image_compression_amd import functional as F_
+from neural_image_compression_amd._lib import LicError
+from neural_image_compression_amd.entropy import (ContextModel, EntropyParameters, FactorizedEntropyBottleneck,
+                                                  MaskedConv2d)
+from neural_image_compression_amd.parallel import shard_batch
+from neural_image_compression_amd.trainer import Trainer
+
+
+@pytest.mark.parametrize("name,cls", [("model_jah_M8_K3.npz", nic.JointAutoregressiveHierarchical),
+                                      ("model_jah_M8_K1.npz", nic.JointAutoregressiveHierarchical),
+                                      ("model_hmr_M8_K3.npz", nic.HierarchicalMixtureResidual)])
+def test_state_dict_matches_reference_layout(golden_dir, name, cls):
+    fx = np.load(os.path.join(golden_dir, name))
+    ks = json.loads(str(fx["keys_shapes"]))
+    sd = cls(int(fx["M"]), int(fx["K"])).state_dict()
+    assert [k for k, _ in ks] == list(sd.keys())          # same keys, same order (Trainer.py:54,65)
+    assert all(tuple(s) == tuple(sd[k].shape) for k, s in ks)
+
+
+def test_constructor_validation():
+    for bad in (0, -1, 1.5, "8"):
+        with pytest.raises(ValueError):
+            nic.JointAutoregressiveHierarchical(bad, 1)       # Models.py:23-24
+        with pytest.raises(ValueError):
+            nic.HierarchicalMixtureResidual(8, bad)           # Models.py:124-125
+    with pytest.raises(ValueError):
+        EntropyParameters(8, 8, 0)                            # ParametersModels.py:12-13
+    m = nic.JointAutoregressiveHierarchical(8, 3)
+    assert (m.M, m.K, m.H, m.distribution) == (8, 3, 8, 'Mixture of Gaussians')
+    assert nic.JointAutoregressiveHierarchical(8, 1).distribution == 'Mean-Scale Gaussian'
+    for attr in ("encoder", "decoder", "hyper_encoder", "hyper_decoder", "factorized_entropy_model",
+                 "context_model", "entropy_parameters", "conditional"):
+        assert hasattr(m, attr)
+
+
+def test_default_init_matches_reference_recipe():
+    fe = FactorizedEntropyBottleneck(5)
+    import math
+    scale = 10.0 ** 0.25
+    for i, out in enumerate((3, 3, 3, 1)):                    # EntropyModels.py:62-86
+        assert torch.allclose(fe.matrices[i], torch.full_like(fe.matrices[i], math.log(math.expm1(1 / scale / out))))
+    assert all((f == 0).all() for f in fe.factors)
+    assert all((b.abs() <= 0.5).all() for b in fe.biases)
+    from neural_image_compression_amd.layers import GDN
+    g = GDN(4)
+    ped = 2.0 ** -36
+    assert torch.allclose(g.beta, torch.sqrt(torch.ones(4) + ped))
+    assert torch.allclose(g.gamma, torch.sqrt(torch.clamp(0.1 * torch.eye(4) + ped, min=ped)))
+    assert set(k for k, _ in g.named_buffers()) == {"beta_reparam.pedestal", "beta_reparam.lower_bound.bound",
+                                                    "gamma_reparam.pedestal", "gamma_reparam.lower_bound.bound"}
+
+
+def test_mask_type_a_has_12_live_taps():
+    m = MaskedConv2d("A", 4, 8, 5, 1, 2)
+    assert int(m.mask[0, 0].sum()) == 12                     # ContextModels.py:12-16
+    assert bin(m._tap_mask).count("1") == 12
+    live = [(t // 5, t % 5) for t in range(25) if (m._tap_mask >> t) & 1]
+    assert all(m.mask[0, 0, r, s] == 1 for r, s in live)
+    with pytest.raises(AssertionError):
+        MaskedConv2d("C", 4, 8, 5, 1, 2)
+    assert ContextModel(4).masked.weight.shape == (8, 4, 5, 5)
+
+
+def test_no_cpu_fallback():
+    """The product path must fail loudly off-GPU (the oracle is never used as a fallback)."""
+    m = nic.JointAutoregressiveHierarchical(8, 1)
+    with pytest.raises(LicError, match="no CPU fallback"):
+        m(torch.rand(1, 3, 64, 64))
+    with pytest.raises(LicError):
+        F_.conv2d(torch.zeros(1, 8, 4, 4), torch.zeros(8, 8, 3, 3), None, 1, 1)
+    with pytest.raises(LicError):
+        nic.rd_loss({"logp_y": torch.zeros(1, 1, 1, 1), "logp_z": torch.zeros(1, 1, 1, 1),
+                     "x_hat": torch.zeros(1, 3, 4, 4)}, torch.zeros(1, 3, 4, 4), 0.01)
+
+
+def test_product_package_never_imports_oracle():
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "neural_image_compression_amd")
+    for dp, _, fns in os.walk(pkg):
+        for fn in fns:
+            if fn.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dp, fn)).read()
+                assert "import oracle" not in txt and "from oracle" not in txt and "lic_oracle" not in txt, fn
+
+
+def test_forward_rejects_bad_spatial_size():
+    m = nic.JointAutoregressiveHierarchical(8, 1)
+    with pytest.raises(RuntimeError, match="multiples of 64"):
+        m(torch.rand(1, 3, 96, 64))
+
+
+def test_shard_batch():
+    assert [shard_batch(10, r, 4) for r in range(4)] == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    assert [shard_batch(256, r, 8) for r in range(8)] == [(32 * r, 32 * r + 32) for r in range(8)]
+
+
+class _FakeModel(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.tensor(1.0))
+        self.calls = []
+
+    def forward(self, x, training=True):
+        self.calls.append(bool(training))
+        return {"v": self.w * x.mean()}
+
+
+def _fake_loss(out, x, lam):
+    return {"loss": (out["v"] - 1.0) ** 2, "bpp_total": 0.5, "psnr": 30.0, "mse": 0.1}
+
+
+class _Rec:
+    def __init__(self):
+        self.rows = []
+
+    def add_scalar(self, tag, v, step):
+        self.rows.append((tag, float(v), int(step)))
+
+    def close(self):
+        pass
+
+
+def test_trainer_step_loop_and_checkpoint(tmp_path):
+    data = [torch.full((2, 3, 4, 4), float(i)) for i in range(3)]
+    model = _FakeModel()
+    opt = torch.optim.SGD(model.parameters(), lr=0.01)
+    ck = str(tmp_path / "ck" / "c.pth")
+    rec = _Rec()
+    with pytest.raises(ValueError):
+        Trainer(model, opt, data, rd_loss=None, device="cpu")          # Trainer.py:18-19
+    t = Trainer(model, opt, data, val_loader=data[:2], rd_loss=_fake_loss, lambda_val=0.01, scheduler='cosine',
+                max_steps=7, val_interval=3, log_interval=1, img_interval=1, checkpoint_path=ck, device="cpu",
+                writer=rec)
+    t.train()
+    assert t.step == 7
+    assert model.calls.count(True) == 7                               # wrap-around over 3 batches
+    assert model.calls.count(False) == 2 * 3                          # validation at steps 0, 3, 6
+    tags = {r[0] for r in rec.rows}
+    assert {"losses/bpp_total", "losses/psnr", "losses/mse", "train/learning_rate",
+            "validation/validation_loss", "validation/validation_bpp", "validation/validation_pnsr"} <= tags
+    assert "losses/loss" not in tags                                  # only floats are logged (Trainer.py:141-143)
+    saved = torch.load(ck)
+    assert set(saved) == {"model", "optimizer", "step", "scheduler"} and saved["step"] == 7
+    t2 = Trainer(_FakeModel(), torch.optim.SGD(model.parameters(), lr=0.01), data, rd_loss=_fake_loss,
+                 max_steps=5, resume=True, checkpoint_path=ck, device="cpu", writer=_Rec())
+    assert t2.step == 7 and t2.max_steps == 12                        # max_steps += step (Trainer.py:70)
+    assert Trainer(_FakeModel(), opt, data, rd_loss=_fake_loss, max_steps=10000, device="cpu",
+                   writer=_Rec()).log_interval == 50                  # max_steps/200 (Trainer.py:27)
