@@ -67,7 +67,10 @@ struct IgemmParams {
 constexpr int IG_BK = 16;
 constexpr int IG_LDA = IG_BK + 4;
 
-template <int BM, int TN, bool VEC>
+// FULLN: every wave of every workgroup has all its TN column tiles live (Npad % (64*TN) == 0), so
+// the MFMA block is branch-free.  (With the scalar branches of the ragged variant hipcc shuffles
+// accumulators through v_accvgpr_read/mov at the joins: ~2 extra AGPR moves per MFMA.)
+template <int BM, int TN, bool VEC, bool FULLN>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   constexpr int BN = 64 * TN;
   constexpr int WM = BM / 2, WN = BN / 2;  // 2x2 waves
@@ -222,16 +225,29 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     }
     // one scalar branch per 32-column tile (n_live is wave-uniform); a single code path keeps
     // every accumulator in one AGPR set
+    __builtin_amdgcn_s_setprio(1);
+    if constexpr (FULLN) {
 #pragma unroll
-    for (int b = 0; b < TN; ++b)
-      if (b < n_live) {
+      for (int t = 0; t < 8; ++t)
 #pragma unroll
-        for (int t = 0; t < 8; ++t)
+        for (int b = 0; b < TN; ++b)
 #pragma unroll
           for (int a = 0; a < TM; ++a)
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][t >> 2][t & 3], rb[b][t >> 2][t & 3],
                                                               acc[a][b], 0, 0, 0);
-      }
+    } else {
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+        if (b < n_live) {
+#pragma unroll
+          for (int t = 0; t < 8; ++t)
+#pragma unroll
+            for (int a = 0; a < TM; ++a)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][t >> 2][t & 3], rb[b][t >> 2][t & 3],
+                                                                acc[a][b], 0, 0, 0);
+        }
+    }
+    __builtin_amdgcn_s_setprio(0);
   };
 
   // chunk cursor for the loads (runs ahead of the compute cursor)
@@ -250,24 +266,28 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     __syncthreads();
     advance();  // cursor -> chunk 1
     load_a(l_tap, l_cb);
-    // Invariant at the top of an iteration on chunk c: sA[c&1] holds chunk c; `ra` holds chunk
-    // c+1 (in flight); rb(c&1) holds B of chunk c; the cursor points at chunk c+1.  Loads past
-    // the last chunk are clamped duplicates, so the body is free of conditionals.
-    for (int c = 0;; c += 2) {
+    // Invariant at the top of an iteration (c even): sA[0] holds chunk c; `ra` holds chunk c+1
+    // (in flight); rb0 holds B of chunk c; the cursor points at chunk c+1.  Loads past the last
+    // chunk are clamped duplicates, so the body is branch-free with a single exit (anything else
+    // makes hipcc copy the 96 accumulators between register sets every iteration).
+    int c = 0;
+    for (; c + 1 < nchunks; c += 2) {
       load_b(rb1, l_tap, l_cb);
       store_a(1);
       advance();
       load_a(l_tap, l_cb);
       compute(0, rb0);
       __syncthreads();
-      if (c + 1 >= nchunks) break;
       load_b(rb0, l_tap, l_cb);
       store_a(0);
       advance();
       load_a(l_tap, l_cb);
       compute(1, rb1);
       __syncthreads();
-      if (c + 2 >= nchunks) break;
+    }
+    if (c < nchunks) {  // odd tail: chunk c is in sA[0] / rb0
+      compute(0, rb0);
+      __syncthreads();
     }
   }
 
@@ -513,21 +533,26 @@ static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& 
   static const int cand[6][2] = {{128, 3}, {64, 3}, {128, 2}, {64, 2}, {128, 1}, {64, 1}};
   int best = 5;
   long best_wg = -1;
-  for (int c = 0; c < 6; ++c) {
-    const int bm = cand[c][0], tn = cand[c][1];
-    if (!p.vec && !(bm == 64 && tn == 1)) continue;  // scalar-A variant exists for one shape only
-    if (p.Npad < 64 * tn && tn > 1 && p.Npad <= 64 * (tn - 1)) continue;  // wider than the problem
-    const long wgs = ((maxP + bm - 1) / bm) * ((p.Npad + 64 * tn - 1) / (64 * tn)) * p.nphase;
-    if (wgs >= 512) {
-      best = c;
-      best_wg = wgs;
-      break;
+  bool found = false;
+  // first pass: shapes whose N tiling comes out full (branch-free MFMA block); second: any
+  for (int pass = 0; pass < 2 && !found; ++pass)
+    for (int c = 0; c < 6; ++c) {
+      const int bm = cand[c][0], tn = cand[c][1];
+      if (!p.vec && !(bm == 64 && tn == 1)) continue;  // scalar-A variant exists for one shape only
+      if (p.Npad < 64 * tn && tn > 1 && p.Npad <= 64 * (tn - 1)) continue;  // wider than the problem
+      if (pass == 0 && p.Npad % (64 * tn) != 0) continue;
+      const long wgs = ((maxP + bm - 1) / bm) * ((p.Npad + 64 * tn - 1) / (64 * tn)) * p.nphase;
+      if (wgs >= 512) {
+        best = c;
+        best_wg = wgs;
+        found = true;
+        break;
+      }
+      if (wgs > best_wg) {
+        best = c;
+        best_wg = wgs;
+      }
     }
-    if (wgs > best_wg) {
-      best = c;
-      best_wg = wgs;
-    }
-  }
   BM = cand[best][0];
   TN = cand[best][1];
   p.NT = (p.Npad + 64 * TN - 1) / (64 * TN);
@@ -560,20 +585,29 @@ LIC_EXPORT int lic_igemm(const lic_igemm_desc* d, lic_stream_t stream) {
   if (rc == 1) return LIC_OK;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)nwg), block(256);
+  const bool full = (p.Npad % (64 * TN)) == 0;
+#define LIC_IGEMM_LAUNCH(bm, tn)                                                        \
+  do {                                                                                  \
+    if (full)                                                                           \
+      hipLaunchKernelGGL((igemm_kernel<bm, tn, true, true>), grid, block, 0, s, p);     \
+    else                                                                                \
+      hipLaunchKernelGGL((igemm_kernel<bm, tn, true, false>), grid, block, 0, s, p);    \
+  } while (0)
   if (!p.vec)  // odd channel counts / unaligned views: scalar-load variant, one tile shape
-    hipLaunchKernelGGL((igemm_kernel<64, 1, false>), grid, block, 0, s, p);
+    hipLaunchKernelGGL((igemm_kernel<64, 1, false, false>), grid, block, 0, s, p);
   else if (BM == 128 && TN == 3)
-    hipLaunchKernelGGL((igemm_kernel<128, 3, true>), grid, block, 0, s, p);
+    LIC_IGEMM_LAUNCH(128, 3);
   else if (BM == 64 && TN == 3)
-    hipLaunchKernelGGL((igemm_kernel<64, 3, true>), grid, block, 0, s, p);
+    LIC_IGEMM_LAUNCH(64, 3);
   else if (BM == 128 && TN == 2)
-    hipLaunchKernelGGL((igemm_kernel<128, 2, true>), grid, block, 0, s, p);
+    LIC_IGEMM_LAUNCH(128, 2);
   else if (BM == 64 && TN == 2)
-    hipLaunchKernelGGL((igemm_kernel<64, 2, true>), grid, block, 0, s, p);
+    LIC_IGEMM_LAUNCH(64, 2);
   else if (BM == 128 && TN == 1)
-    hipLaunchKernelGGL((igemm_kernel<128, 1, true>), grid, block, 0, s, p);
+    LIC_IGEMM_LAUNCH(128, 1);
   else
-    hipLaunchKernelGGL((igemm_kernel<64, 1, true>), grid, block, 0, s, p);
+    LIC_IGEMM_LAUNCH(64, 1);
+#undef LIC_IGEMM_LAUNCH
   return lic_check_launch();
 }
 
@@ -608,7 +642,7 @@ struct WgradParams {
 
 constexpr int WG_BK = 16;
 
-template <int TM, int TN, bool VEC>
+template <int TM, int TN, bool VEC, bool FULL>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   constexpr int BMt = 64 * TM, BNt = 64 * TN;
   constexpr int WM = BMt / 2, WN = BNt / 2;
@@ -719,17 +753,27 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     for (int b = 0; b < TN; ++b)
 #pragma unroll
       for (int t = 0; t < 8; ++t) bf[b][t] = sB[buf][(lh * 8 + t) * BNt + wn0 + b * 32 + li];
+    if constexpr (FULL) {  // all sub-tiles live everywhere: branch-free MFMA block
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
-      if (a < m_live) {
+      for (int t = 0; t < 8; ++t)
 #pragma unroll
-        for (int b = 0; b < TN; ++b)
-          if (b < n_live) {
+        for (int a = 0; a < TM; ++a)
 #pragma unroll
-            for (int t = 0; t < 8; ++t)
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][t], bf[b][t], acc[a][b], 0, 0, 0);
-          }
-      }
+          for (int b = 0; b < TN; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][t], bf[b][t], acc[a][b], 0, 0, 0);
+    } else {
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+        if (a < m_live) {
+#pragma unroll
+          for (int b = 0; b < TN; ++b)
+            if (b < n_live) {
+#pragma unroll
+              for (int t = 0; t < 8; ++t)
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][t], bf[b][t], acc[a][b], 0, 0, 0);
+            }
+        }
+    }
   };
 
   if (nloc > 0) {
@@ -737,17 +781,20 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     store_chunk(0);
     __syncthreads();
     load_chunk(c_begin + 1);
-    for (int c = 0;; c += 2) {
+    int c = 0;
+    for (; c + 1 < nloc; c += 2) {  // branch-free body, single exit (see igemm_kernel)
       store_chunk(1);
       load_chunk(c_begin + c + 2);
       compute(0);
       __syncthreads();
-      if (c + 1 >= nloc) break;
       store_chunk(0);
       load_chunk(c_begin + c + 3);
       compute(1);
       __syncthreads();
-      if (c + 2 >= nloc) break;
+    }
+    if (c < nloc) {
+      compute(0);
+      __syncthreads();
     }
   }
   float* slab = p.slabs + ((long)split * p.ntaps + tap) * p.row.C * p.col.C;
@@ -863,18 +910,27 @@ LIC_EXPORT int lic_wgrad(const lic_wgrad_desc* d, void* workspace, size_t worksp
   p.dW = make_fastdiv((unsigned)d->Ws);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(pl.MTt * pl.NTt, pl.ntaps, pl.splitk), block(256);
+  const bool full = (pl.Cm % (64 * pl.TM) == 0) && (pl.Cn % (64 * pl.TN) == 0);
+#define LIC_WGRAD_LAUNCH(tm, tn)                                                      \
+  do {                                                                                \
+    if (full)                                                                         \
+      hipLaunchKernelGGL((wgrad_kernel<tm, tn, true, true>), grid, block, 0, s, p);   \
+    else                                                                              \
+      hipLaunchKernelGGL((wgrad_kernel<tm, tn, true, false>), grid, block, 0, s, p);  \
+  } while (0)
   if (!pl.vec)
-    hipLaunchKernelGGL((wgrad_kernel<1, 1, false>), grid, block, 0, s, p);
+    hipLaunchKernelGGL((wgrad_kernel<1, 1, false, false>), grid, block, 0, s, p);
   else if (pl.TM == 2 && pl.TN == 3)
-    hipLaunchKernelGGL((wgrad_kernel<2, 3, true>), grid, block, 0, s, p);
+    LIC_WGRAD_LAUNCH(2, 3);
   else if (pl.TM == 2 && pl.TN == 2)
-    hipLaunchKernelGGL((wgrad_kernel<2, 2, true>), grid, block, 0, s, p);
+    LIC_WGRAD_LAUNCH(2, 2);
   else if (pl.TM == 2 && pl.TN == 1)
-    hipLaunchKernelGGL((wgrad_kernel<2, 1, true>), grid, block, 0, s, p);
+    LIC_WGRAD_LAUNCH(2, 1);
   else if (pl.TM == 1 && pl.TN == 3)
-    hipLaunchKernelGGL((wgrad_kernel<1, 3, true>), grid, block, 0, s, p);
+    LIC_WGRAD_LAUNCH(1, 3);
   else
-    hipLaunchKernelGGL((wgrad_kernel<1, 1, true>), grid, block, 0, s, p);
+    LIC_WGRAD_LAUNCH(1, 1);
+#undef LIC_WGRAD_LAUNCH
   rc = lic_check_launch();
   if (rc != LIC_OK) return rc;
   const long total = (long)pl.ntaps * pl.Cm * pl.Cn;
