@@ -46,8 +46,9 @@ def cpu_baseline(M, K, H, W, lam, budget_s=25.0):
     import golden_recipe as R
     import neural_image_compression_amd as nic
     from oracle import oracle as O
-    cores = len(os.sched_getaffinity(0))
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    # a one-GPU box's CPU share is 16 cores: use at most that many OpenMP threads
+    cores = min(len(os.sched_getaffinity(0)), int(os.environ.get("LIC_CPU_BASELINE_THREADS", "16")))
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     m = nic.JointAutoregressiveHierarchical(M, K)
     ks = [(k, tuple(v.shape)) for k, v in m.state_dict().items()]
     st = R.make_state(ks, 0)
@@ -159,9 +160,19 @@ def main():
             dom = max(agg, key=lambda k: agg[k][1])
             n, secs, flops, abytes = agg[dom]
             ach = flops / secs / 1e12
+            # HBM bytes per launch from the committed PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE
+            # runs of this same command, gfx950 x2 read correction applied; see the file's "_how")
+            traffic = None
+            try:
+                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+                for kname, v in pmc.items():
+                    if dom in kname and (H, W, B, M, K) == (256, 256, 32, 192, 1):
+                        traffic = v["traffic_bytes_per_launch"]
+            except Exception:
+                traffic = None
             line["roofline"] = {
                 "kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": FP32_MFMA_PEAK_TF,
-                "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TF, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(ach / FP32_MFMA_PEAK_TF, 4), "traffic": traffic,
                 "launches": n, "avg_launch_ms": round(secs / n * 1e3, 4),
                 "alg_gflop_per_launch": round(flops / n / 1e9, 3),
                 "hbm_frac_of_alg_bytes": round(abytes / secs / 1e9 / HBM_PEAK_GBS, 4),

@@ -116,8 +116,11 @@ def _igemm(inp, w_packed, out, *, B, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, 
     L.check(lib.lic_igemm(C.byref(d), _stream()), "lic_igemm")
     e1.record()
     act_bytes = 4 * (B * Hi * Wi * Cin + B * Ho * Wo * Cout)
-    vec = "true" if (Cin % 4 == 0 and d.in_ld % 4 == 0) else "false"
-    PROFILE.append((f"igemm_kernel<{bm.value}, {bn.value // 64}, {vec}>", 2 * macs.value, act_bytes, e0, e1))
+    vec = Cin % 4 == 0 and d.in_ld % 4 == 0
+    tn = bn.value // 64
+    full = vec and ((Cout + 31) // 32 * 32) % (64 * tn) == 0
+    name = f"igemm_kernel<{bm.value}, {tn}, {str(vec).lower()}, {str(full).lower()}>"  # as rocprofv3 prints it
+    PROFILE.append((name, 2 * macs.value, act_bytes, e0, e1))
 
 
 def _wgrad(p, g, dst, *, B, Hs, Ws, Cp, Hl, Wl, Cg, kh, kw, stride, pad, g_is_row, dst_sm, dst_sn,
