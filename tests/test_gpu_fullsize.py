@@ -1,0 +1,207 @@
+"""GPU tests at BASELINE.json's full sizes: size-independent properties (batch-split invariance,
+run-to-run bitwise determinism, linearity, loss identities, quantisation idempotence) plus one
+full-capacity image against the CPU oracle.  Run with: python -m pytest tests -m gpu"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import golden_recipe as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import neural_image_compression_amd as nic
+    from neural_image_compression_amd import functional as F_
+    from oracle import oracle as O
+    return nic, F_, O, torch.device("cuda:0")
+
+
+def build(nic, cls, M, K, dev, seed=0):
+    torch.manual_seed(seed)
+    return cls(M, K).to(dev)
+
+
+def rand_images(B, H, W, dev, seed=1234):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return torch.rand(B, 3, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+
+
+def test_cfg2_batch_split_invariance_and_determinism(env):
+    """Config 2 at full size (JAH 192/K=1, 32x3x256x256): every image is independent, so the
+    batch-32 result must equal, bit for bit, the two batch-16 results; and a second run must
+    reproduce the first bit for bit (fixed-order split-K, no float atomics)."""
+    nic, F_, O, dev = env
+    model = build(nic, nic.JointAutoregressiveHierarchical, 192, 1, dev)
+    x = rand_images(32, 256, 256, dev)
+    model.eval()
+    with torch.no_grad():
+        full = model(x, training=False)
+        again = model(x, training=False)
+        lo = model(x[:16].contiguous(memory_format=torch.channels_last), training=False)
+        hi = model(x[16:].contiguous(memory_format=torch.channels_last), training=False)
+    for k in ("y", "z", "y_in", "z_in", "x_hat", "logp_y", "logp_z", "mu", "sigma"):
+        assert torch.equal(full[k], again[k]), f"{k}: run-to-run mismatch"
+        assert torch.equal(full[k][:16], lo[k]) and torch.equal(full[k][16:], hi[k]), f"{k}: batch split"
+    # quantisation idempotence and likelihood range (Models.py:63-64, EntropyModels.py:31)
+    assert torch.equal(full["y_in"], torch.round(full["y"])) and torch.equal(full["z_in"], torch.round(full["z"]))
+    for k in ("p_y", "p_z"):
+        assert float(full[k].min()) >= 1e-9 and float(full[k].max()) <= 1.0 + 1e-6
+    assert tuple(full["x_hat"].shape) == (32, 3, 256, 256) and tuple(full["y"].shape) == (32, 192, 16, 16)
+    assert tuple(full["z"].shape) == (32, 192, 4, 4)
+
+
+def test_cfg2_training_step_identities_and_grad_determinism(env):
+    nic, F_, O, dev = env
+    model = build(nic, nic.JointAutoregressiveHierarchical, 192, 1, dev)
+    x = rand_images(32, 256, 256, dev)
+    g = torch.Generator(device="cpu").manual_seed(4321)
+    uz = torch.rand(32, 192, 4, 4, generator=g).to(dev)
+    uy = torch.rand(32, 192, 16, 16, generator=g).to(dev)
+    lam = 0.01
+    grads = []
+    for _ in range(2):
+        model.zero_grad(set_to_none=True)
+        out = model(x, noise=(uz, uy))
+        res = nic.rd_loss(out, x, lam)
+        res["loss"].backward()
+        grads.append([p.grad.clone() for p in model.parameters()])
+    assert all(torch.equal(a, b) for a, b in zip(*grads)), "gradients differ between identical runs"
+    assert all(torch.isfinite(g_).all() for g_ in grads[0])
+    # rd_loss identities (RateDistortionLoss.py:13-34) recomputed with torch reductions on device
+    ln2 = math.log(2.0)
+    bits_y = (-out["logp_y"].double().sum(dim=(1, 2, 3)) / ln2)
+    bits_z = (-out["logp_z"].double().sum(dim=(1, 2, 3)) / ln2)
+    mse_img = ((out["x_hat"].double() - x.double()) ** 2).mean(dim=(1, 2, 3))
+    assert abs(res["bits_y"] - float(bits_y.mean())) <= 1e-5 * abs(res["bits_y"])
+    assert abs(res["bits_z"] - float(bits_z.mean())) <= 1e-5 * abs(res["bits_z"])
+    assert abs(res["bpp_y"] - float(bits_y.mean()) / 65536) <= 1e-5 * res["bpp_y"]
+    assert abs(res["mse"] - float(mse_img.mean())) <= 1e-5 * res["mse"]
+    assert abs(res["psnr"] - (-10 * math.log10(res["mse"] + 1e-8))) <= 1e-4
+    assert abs(float(res["loss"]) - (res["bpp_total"] + lam * 255 ** 2 * res["mse"])) <= 1e-5 * abs(float(res["loss"]))
+    assert torch.allclose(res["mse_per_image"].double(), mse_img, rtol=1e-5)
+    # noise relaxation: y_in - y == u - 0.5 exactly as computed (Models.py:57-58)
+    assert torch.equal(out["y_in"], out["y"] + (uy - 0.5)) and torch.equal(out["z_in"], out["z"] + (uz - 0.5))
+
+
+def test_full_capacity_image_vs_oracle(env):
+    """One 256x256 image through JAH(192, K=1) forward + rd_loss + backward against the CPU oracle
+    (1e-4 relative on activations / losses; gradients relative to each tensor's scale)."""
+    nic, F_, O, dev = env
+    M, K, lam = 192, 1, 0.01
+    model = nic.JointAutoregressiveHierarchical(M, K)
+    ks = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    st = R.make_state(ks, 77)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
+    model = model.to(dev)
+    x = R.make_image(1, 256, 256, 78)
+    uz, uy = R.make_noise((1, M, 4, 4), 79), R.make_noise((1, M, 16, 16), 80)
+    tx = torch.from_numpy(x).to(dev).contiguous(memory_format=torch.channels_last)
+    out = model(tx, noise=(torch.from_numpy(uz).to(dev), torch.from_numpy(uy).to(dev)))
+    res = nic.rd_loss(out, tx, lam)
+    res["loss"].backward()
+    o_out, o_loss, o_grads = O.model_forward(dict(st), x, M, K, "5x5", training=True, noise=(uz, uy),
+                                             lambda_rd=lam, backward=True)
+
+    def close(a, b, what, rtol=1e-4, atol=1e-4):
+        a, b = a.detach().cpu().numpy().astype(np.float64), np.asarray(b, np.float64)
+        err = np.abs(a - b)
+        assert (err <= atol + rtol * np.abs(b)).all(), f"{what}: max err {err.max():.3e}"
+    close(out["y"], o_out["y"], "y")
+    close(out["z"], o_out["z"], "z")
+    close(out["x_hat"], o_out["x_hat"], "x_hat")
+    close(out["logp_z"], o_out["logp_z"], "logp_z", 1e-4, 1e-5)
+    for k in ("bpp_y", "bpp_z", "bpp_total", "mse", "psnr"):
+        assert abs(res[k] - o_loss[k]) <= 1e-4 * abs(o_loss[k]), (k, res[k], o_loss[k])
+    worst = ("", 0.0)
+    for name, p in model.named_parameters():
+        ref = o_grads[name]
+        scale = max(np.abs(ref).max(), 1e-12)
+        e = float(np.abs(p.grad.detach().cpu().numpy() - ref).max() / scale)
+        if e > worst[1]:
+            worst = (name, e)
+    assert worst[1] <= 5e-4, worst
+
+
+def test_conv_linearity_at_full_size(env):
+    """conv(a*x1 + b*x2) - bias == a*(conv(x1)-bias) + b*(conv(x2)-bias) on the largest layer
+    (5x5 s2 192->192 at 128^2, batch 32) and on its transposed counterpart."""
+    nic, F_, O, dev = env
+    torch.manual_seed(5)
+    w = torch.randn(192, 192, 5, 5, device=dev) / math.sqrt(192 * 25)
+    bias = torch.randn(192, device=dev)
+    x1 = torch.randn(32, 192, 128, 128, device=dev).contiguous(memory_format=torch.channels_last)
+    x2 = torch.randn(32, 192, 128, 128, device=dev).contiguous(memory_format=torch.channels_last)
+    a, b = 0.75, -1.5
+    with torch.no_grad():
+        lhs = F_.conv2d(a * x1 + b * x2, w, bias, 2, 2) - bias.view(1, -1, 1, 1)
+        rhs = a * (F_.conv2d(x1, w, bias, 2, 2) - bias.view(1, -1, 1, 1)) + \
+            b * (F_.conv2d(x2, w, bias, 2, 2) - bias.view(1, -1, 1, 1))
+        scale = float(rhs.abs().max())
+        assert float((lhs - rhs).abs().max()) <= 2e-5 * scale
+        del lhs, rhs
+        x1s, x2s = x1[:, :, :64, :64].contiguous(memory_format=torch.channels_last), \
+            x2[:, :, :64, :64].contiguous(memory_format=torch.channels_last)
+        lhs = F_.conv_transpose2d(a * x1s + b * x2s, w, None, 2, 2, 1)
+        rhs = a * F_.conv_transpose2d(x1s, w, None, 2, 2, 1) + b * F_.conv_transpose2d(x2s, w, None, 2, 2, 1)
+        assert float((lhs - rhs).abs().max()) <= 2e-5 * float(rhs.abs().max())
+
+
+def test_gdn_identity_at_full_size(env):
+    """GDN then IGDN with the same parameters is the identity: x * rsqrt(n(x)) ... and at the layer
+    level out^2 * norm == x^2 (checked through the public module with default parameters)."""
+    nic, F_, O, dev = env
+    from neural_image_compression_amd.layers import GDN
+    g = GDN(192).to(dev)
+    x = torch.randn(32, 192, 64, 64, device=dev).contiguous(memory_format=torch.channels_last)
+    with torch.no_grad():
+        y = g(x)
+        beta = torch.clamp_min(g.beta, g.beta_reparam.bound_value) ** 2 - g.beta_reparam.pedestal_value
+        gamma = torch.clamp_min(g.gamma, g.gamma_reparam.bound_value) ** 2 - g.gamma_reparam.pedestal_value
+        norm = torch.einsum("ij,bjhw->bihw", gamma.double(), x.double() ** 2) + beta.double().view(1, -1, 1, 1)
+        ref = x.double() / norm.sqrt()
+        assert float((y.double() - ref).abs().max()) <= 1e-5 * float(ref.abs().max())
+
+
+def test_cfg4_and_cfg5_shapes_run(env):
+    """Config 4 (JAH 192/K=3, batch 32, train step) and config 5 (16x3x512x512, eval): shapes of the
+    13-key dict (Models.py:92-106) and finite losses."""
+    nic, F_, O, dev = env
+    model = build(nic, nic.JointAutoregressiveHierarchical, 192, 3, dev)
+    x = rand_images(32, 256, 256, dev)
+    out = model(x)
+    res = nic.rd_loss(out, x, 0.01)
+    res["loss"].backward()
+    assert set(out) == {"x_hat", "y", "y_in", "z", "z_in", "p_z", "logp_z", "p_y", "logp_y", "training",
+                        "weights", "mus", "sigmas"}
+    assert tuple(out["weights"].shape) == (32, 3, 192, 16, 16) == tuple(out["sigmas"].shape)
+    assert torch.allclose(out["weights"].sum(dim=1), torch.ones_like(out["weights"][:, 0]), atol=1e-5)
+    assert float(out["sigmas"].min()) >= 1e-6
+    assert math.isfinite(float(res["loss"])) and all(torch.isfinite(p.grad).all() for p in model.parameters())
+    del out, res
+    model.zero_grad(set_to_none=True)
+    x5 = rand_images(16, 512, 512, dev, seed=5)
+    model.eval()
+    with torch.no_grad():
+        out5 = model(x5, training=False)
+        res5 = nic.rd_loss(out5, x5, 0.01)
+    assert tuple(out5["y"].shape) == (16, 192, 32, 32) and tuple(out5["z"].shape) == (16, 192, 8, 8)
+    assert tuple(out5["x_hat"].shape) == (16, 3, 512, 512) and math.isfinite(res5["psnr"])
+    assert torch.equal(out5["y_in"], torch.round(out5["y"]))
+
+
+def test_hmr_full_capacity_runs(env):
+    """HierarchicalMixtureResidual(192, K=3) (3x3 residual stacks) train step at 4x3x256x256."""
+    nic, F_, O, dev = env
+    model = build(nic, nic.HierarchicalMixtureResidual, 192, 3, dev)
+    x = rand_images(4, 256, 256, dev)
+    out = model(x)
+    res = nic.rd_loss(out, x, 0.01)
+    res["loss"].backward()
+    assert tuple(out["y"].shape) == (4, 192, 16, 16) and math.isfinite(float(res["loss"]))
+    assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
