@@ -676,57 +676,48 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.0f;
 
-  // per-thread load slots: (pixel row kr within the chunk, channel c4)
-  int a_kr[APASS], a_c4[APASS], b_kr[BPASS], b_c4[BPASS];
-#pragma unroll
-  for (int j = 0; j < APASS; ++j) {
-    const int idx = tid + 256 * j;
-    a_kr[j] = idx / (BMt / 4);
-    a_c4[j] = (idx % (BMt / 4)) * 4;
-  }
-#pragma unroll
-  for (int j = 0; j < BPASS; ++j) {
-    const int idx = tid + 256 * j;
-    b_kr[j] = idx / (BNt / 4);
-    b_c4[j] = (idx % (BNt / 4)) * 4;
-  }
-
+  // Load slots: thread t owns pixel row kr = t/16 of every chunk and, within it, the float4 at
+  // channel (t%16)*4 + 64*j of each operand -- one pixel decode per thread per chunk serves all
+  // its loads, and 16 lanes cover 256 contiguous bytes.
+  static_assert(APASS == TM && BPASS == TN, "one float4 per 64 channels per thread");
+  const int kr = tid >> 4, c16 = (tid & 15) * 4;
   f32x4 ra[APASS], rb[BPASS];
   bool ra_ok[APASS], rb_ok[BPASS];
   const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-  auto load_op = [&](const WgOperand& op, long pk, int ch, f32x4& v, bool& okr) {
-    bool ok = pk < p.Ps;
-    long pix = ok ? pk : 0;
-    if (op.gathered) {
-      const int b = fdiv((int)pix, p.dHW);
-      const int rem = (int)pix - b * p.Hs * p.Ws;
-      const int hs = fdiv(rem, p.dW), ws = rem - hs * p.Ws;
-      const int hl = hs * p.stride - p.pad + r, wl = ws * p.stride - p.pad + s;
-      ok = ok && hl >= 0 && wl >= 0 && hl < p.Hl && wl < p.Wl;
-      pix = ((long)b * p.Hl + hl) * p.Wl + wl;
-    }
-    if (VEC) {
-      ok = ok && ch < op.C;
-      v = *reinterpret_cast<const f32x4*>(op.ptr + (ok ? pix * op.ld + ch : 0L));
-      okr = ok;
-    } else {
-      v = zero4;
-      if (ok) {
-        const float* src = op.ptr + pix * op.ld + ch;
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          if (ch + e < op.C) v[e] = src[e];
-      }
-      okr = true;
-    }
-  };
   // chunk indices past the end are clamped to the last one (harmless duplicate loads)
   auto load_chunk = [&](int c) {
-    const long k0 = (long)(c < c_end ? c : c_end - 1) * WG_BK;
+    const long pk = (long)(c < c_end ? c : c_end - 1) * WG_BK + kr;
+    const bool inb = pk < p.Ps;
+    const long pix = inb ? pk : 0;
+    // gathered position of this pixel on the large grid (used by whichever operand is gathered)
+    const int b = fdiv((int)pix, p.dHW);
+    const int rem = (int)pix - b * p.Hs * p.Ws;
+    const int hs = fdiv(rem, p.dW), ws = rem - hs * p.Ws;
+    const int hl = hs * p.stride - p.pad + r, wl = ws * p.stride - p.pad + s;
+    const bool gok = inb && hl >= 0 && wl >= 0 && hl < p.Hl && wl < p.Wl;
+    const long gpix = ((long)b * p.Hl + hl) * p.Wl + wl;
+    auto load_op = [&](const WgOperand& op, int ch, f32x4& v, bool& okr) {
+      bool ok = op.gathered ? gok : inb;
+      const long px = op.gathered ? gpix : pix;
+      if (VEC) {
+        ok = ok && ch < op.C;
+        v = *reinterpret_cast<const f32x4*>(op.ptr + (ok ? px * op.ld + ch : 0L));
+        okr = ok;
+      } else {
+        v = zero4;
+        if (ok) {
+          const float* src = op.ptr + px * op.ld + ch;
 #pragma unroll
-    for (int j = 0; j < APASS; ++j) load_op(p.row, k0 + a_kr[j], m0 + a_c4[j], ra[j], ra_ok[j]);
+          for (int e = 0; e < 4; ++e)
+            if (ch + e < op.C) v[e] = src[e];
+        }
+        okr = true;
+      }
+    };
 #pragma unroll
-    for (int j = 0; j < BPASS; ++j) load_op(p.col, k0 + b_kr[j], n0 + b_c4[j], rb[j], rb_ok[j]);
+    for (int j = 0; j < APASS; ++j) load_op(p.row, m0 + c16 + 64 * j, ra[j], ra_ok[j]);
+#pragma unroll
+    for (int j = 0; j < BPASS; ++j) load_op(p.col, n0 + c16 + 64 * j, rb[j], rb_ok[j]);
   };
   const bool sqa = p.row.sq != 0, sqb = p.col.sq != 0;
   auto store_chunk = [&](int buf) {
@@ -734,13 +725,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     for (int j = 0; j < APASS; ++j) {
       f32x4 v = ra_ok[j] ? ra[j] : zero4;
       v = sqa ? v * v : v;
-      *reinterpret_cast<f32x4*>(&sA[buf][a_kr[j] * BMt + a_c4[j]]) = v;
+      *reinterpret_cast<f32x4*>(&sA[buf][kr * BMt + c16 + 64 * j]) = v;
     }
 #pragma unroll
     for (int j = 0; j < BPASS; ++j) {
       f32x4 v = rb_ok[j] ? rb[j] : zero4;
       v = sqb ? v * v : v;
-      *reinterpret_cast<f32x4*>(&sB[buf][b_kr[j] * BNt + b_c4[j]]) = v;
+      *reinterpret_cast<f32x4*>(&sB[buf][kr * BNt + c16 + 64 * j]) = v;
     }
   };
   auto compute = [&](int buf) {
