@@ -174,8 +174,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
       bool ok = a_ok[j] && nh >= 0 && nw >= 0 && ih < p.Hi && iw < p.Wi;
       if (VEC) {
         ok = ok && ci < p.Cin;
-        const long off = ok ? (long)(a_base[j] + ih * p.Wi + iw) * p.in_ld + ci : 0L;
-        ra[j] = *reinterpret_cast<const f32x4*>(p.in + off);
+        // 32-bit selects (not a branch): the load must stay in the MFMA's basic block
+        const int okm = -(int)ok;  // all-ones / zero mask: arithmetic keeps hipcc from branching
+        const int pixi = (a_base[j] + ih * p.Wi + iw) & okm;
+        const int cc = ci & okm;
+        ra[j] = *reinterpret_cast<const f32x4*>(p.in + ((long)pixi * p.in_ld + cc));
         ra_ok[j] = ok;
       } else {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     }
     // one scalar branch per 32-column tile (n_live is wave-uniform); a single code path keeps
     // every accumulator in one AGPR set
-    __builtin_amdgcn_s_setprio(1);
+    if constexpr (!FULLN) __builtin_amdgcn_s_setprio(1);
     if constexpr (FULLN) {
 #pragma unroll
       for (int t = 0; t < 8; ++t)
@@ -247,7 +250,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
                                                                 acc[a][b], 0, 0, 0);
         }
     }
-    __builtin_amdgcn_s_setprio(0);
+    if constexpr (!FULLN) __builtin_amdgcn_s_setprio(0);
   };
 
   // chunk cursor for the loads (runs ahead of the compute cursor)
@@ -270,6 +273,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     // (in flight); rb0 holds B of chunk c; the cursor points at chunk c+1.  Loads past the last
     // chunk are clamped duplicates, so the body is branch-free with a single exit (anything else
     // makes hipcc copy the 96 accumulators between register sets every iteration).
+    // Ask the scheduler to thread the next chunk's address arithmetic, global loads and LDS store
+    // between this chunk's MFMAs (each 32x32x2 f32 MFMA leaves ~15 free issue slots).  Without
+    // this the non-MFMA work sits in front of the burst, and the two waves sharing a SIMD -- which
+    // interleave MFMA by MFMA and therefore run in lockstep -- idle the matrix pipe together.
+    auto interleave = [&]() {
+#pragma unroll
+      for (int i = 0; i < TM * TN * 8; ++i) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // 1 MFMA
+        __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);  // up to 4 VALU/SALU
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // up to 1 VMEM read
+        __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);  // up to 1 DS write
+      }
+    };
     int c = 0;
     for (; c + 1 < nchunks; c += 2) {
       load_b(rb1, l_tap, l_cb);
@@ -277,12 +293,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
       advance();
       load_a(l_tap, l_cb);
       compute(0, rb0);
+      if constexpr (FULLN) interleave();
       __syncthreads();
       load_b(rb0, l_tap, l_cb);
       store_a(0);
       advance();
       load_a(l_tap, l_cb);
       compute(1, rb1);
+      if constexpr (FULLN) interleave();
       __syncthreads();
     }
     if (c < nchunks) {  // odd tail: chunk c is in sA[0] / rb0

@@ -1,0 +1,222 @@
+"""Second CPU restatement of the hot path, written with plain torch ops (torch.nn.functional on
+CPU, autograd for the backward): the closest thing to "the reference's PyTorch CPU path" that can
+run where the reference itself cannot travel.  TEST INFRASTRUCTURE ONLY (same rules as
+lic_oracle.c): used by tests/ as a cross-check of the C oracle and of the HIP path at sizes where
+oneDNN is much faster than the plain-C loops, and by bench.py's cpu_baseline leg.
+
+Restates (paths under /root/reference): Models.py:49-106,148-205; Components.py:6-122;
+Layers.py:18-119; ContextModels.py:9-20; ParametersModels.py:20-64; EntropyModels.py:29-31,
+88-151,192-233; utils.py:6-8; RateDistortionLoss.py:5-49; GDN per SURVEY.md Appendix B
+(third-party compressai: parity unpinned).  Parameters: a state dict with the reference's keys.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, Optional, Tuple
+
+import torch
+import torch.nn.functional as F
+
+PEDESTAL = float(2.0 ** -36)
+
+
+class _LowerBound(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bound):
+        ctx.save_for_backward(x)
+        ctx.bound = bound
+        return torch.clamp_min(x, bound)
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return ((x >= ctx.bound) | (g < 0)).to(g.dtype) * g, None
+
+
+def _gdn(x, P, pre, inverse):
+    C = x.size(1)
+    beta = _LowerBound.apply(P[pre + ".beta"], (1e-6 + PEDESTAL) ** 0.5) ** 2 - PEDESTAL
+    gamma = _LowerBound.apply(P[pre + ".gamma"], PEDESTAL ** 0.5) ** 2 - PEDESTAL
+    norm = F.conv2d(x * x, gamma.reshape(C, C, 1, 1), beta)
+    return x * (torch.sqrt(norm) if inverse else torch.rsqrt(norm))
+
+
+def _conv(x, P, pre, s, p):
+    return F.conv2d(x, P[pre + ".weight"], P[pre + ".bias"], stride=s, padding=p)
+
+
+def _convT(x, P, pre, s, p, op):
+    return F.conv_transpose2d(x, P[pre + ".weight"], P[pre + ".bias"], stride=s, padding=p, output_padding=op)
+
+
+def _lrelu(x):
+    return F.leaky_relu(x, 0.01)
+
+
+def _rb_stride(x, P, pre):
+    out = _gdn(_conv(_lrelu(_conv(x, P, pre + ".conv1", 2, 1)), P, pre + ".conv2", 1, 1), P, pre + ".gdn", False)
+    idn = _conv(x, P, pre + ".skip", 2, 0) if (pre + ".skip.weight") in P else x
+    return out + idn
+
+
+def _rb(x, P, pre):
+    out = _lrelu(_conv(_lrelu(_conv(x, P, pre + ".conv1", 1, 1)), P, pre + ".conv2", 1, 1))
+    idn = _conv(x, P, pre + ".skip", 1, 0) if (pre + ".skip.weight") in P else x
+    return out + idn
+
+
+def _rb_up(x, P, pre):
+    out = _lrelu(_convT(x, P, pre + ".subpel_conv.deconv", 2, 1, 1))
+    out = _gdn(_conv(out, P, pre + ".conv", 1, 1), P, pre + ".igdn", True)
+    return out + _convT(x, P, pre + ".upsample.deconv", 2, 1, 1)
+
+
+def encoder(x, P, kind):
+    p = "encoder.net."
+    if kind == "5x5":
+        h = _gdn(_conv(x, P, p + "0", 2, 2), P, p + "1", False)
+        h = _gdn(_conv(h, P, p + "2", 2, 2), P, p + "3", False)
+        h = _gdn(_conv(h, P, p + "4", 2, 2), P, p + "5", False)
+        return _conv(h, P, p + "6", 2, 2)
+    h = _rb(_rb_stride(x, P, p + "0"), P, p + "1")
+    h = _rb(_rb_stride(h, P, p + "2"), P, p + "3")
+    h = _rb(_rb_stride(h, P, p + "4"), P, p + "5")
+    return _conv(h, P, p + "6", 2, 1)
+
+
+def decoder(y, P, kind):
+    p = "decoder.net."
+    if kind == "5x5":
+        h = _gdn(_convT(y, P, p + "0", 2, 2, 1), P, p + "1", True)
+        h = _gdn(_convT(h, P, p + "2", 2, 2, 1), P, p + "3", True)
+        h = _gdn(_convT(h, P, p + "4", 2, 2, 1), P, p + "5", True)
+        return _convT(h, P, p + "6", 2, 2, 1)
+    h = _rb_up(_rb(y, P, p + "0"), P, p + "1")
+    h = _rb_up(_rb(h, P, p + "2"), P, p + "3")
+    h = _rb_up(_rb(h, P, p + "4"), P, p + "5")
+    return _convT(_rb(h, P, p + "6"), P, p + "7.deconv", 2, 1, 1)
+
+
+def hyper_encoder(y, P, kind):
+    p = "hyper_encoder.net."
+    if kind == "5x5":
+        h = _lrelu(_conv(y, P, p + "0", 1, 1))
+        h = _lrelu(_conv(h, P, p + "2", 2, 2))
+        return _conv(h, P, p + "4", 2, 2)
+    h = _lrelu(_conv(y, P, p + "0", 1, 1))
+    h = _lrelu(_conv(h, P, p + "2", 1, 1))
+    h = _lrelu(_conv(h, P, p + "4", 2, 1))
+    h = _lrelu(_conv(h, P, p + "6", 1, 1))
+    return _conv(h, P, p + "8", 2, 1)
+
+
+def hyper_decoder(z, P, kind):
+    p = "hyper_decoder.net."
+    if kind == "5x5":
+        h = _lrelu(_convT(z, P, p + "0", 2, 2, 1))
+        h = _lrelu(_convT(h, P, p + "2", 2, 2, 1))
+        return _conv(h, P, p + "4", 1, 1)
+    h = _lrelu(_conv(z, P, p + "0", 1, 1))
+    h = _lrelu(_convT(h, P, p + "2.deconv", 2, 1, 1))
+    h = _lrelu(_conv(h, P, p + "4", 1, 1))
+    h = _lrelu(_convT(h, P, p + "6.deconv", 2, 1, 1))
+    return _conv(h, P, p + "8", 1, 1)
+
+
+def _factorized(x, P):
+    """EntropyModels.py:88-151 (sign trick with detached sign)."""
+    pre = "factorized_entropy_model."
+    C = x.size(1)
+    flat = x.transpose(0, 1).reshape(C, 1, -1)
+
+    def logits(v):
+        for i in range(4):
+            v = torch.matmul(F.softplus(P[pre + f"matrices.{i}"]), v) + P[pre + f"biases.{i}"]
+            if i < 3:
+                v = v + torch.tanh(P[pre + f"factors.{i}"]) * torch.tanh(v)
+        return v
+    lower, upper = logits(flat - 0.5), logits(flat + 0.5)
+    s = -torch.sign(lower + upper).detach()
+    pmf = torch.abs(torch.sigmoid(s * upper) - torch.sigmoid(s * lower))
+    return pmf.reshape(C, x.size(0), *x.shape[2:]).transpose(0, 1)
+
+
+def _gcdf(t):
+    return 0.5 * (1.0 + torch.erf(t / math.sqrt(2.0)))
+
+
+def forward(P: Dict[str, torch.Tensor], x: torch.Tensor, M: int, K: int, kind: str = "5x5",
+            training: bool = True, noise: Optional[Tuple[torch.Tensor, torch.Tensor]] = None):
+    """Returns the reference's 13-key dict (Models.py:92-106)."""
+    y = encoder(x, P, kind)
+    z = hyper_encoder(y, P, kind)
+    if training:
+        uz, uy = noise if noise is not None else (torch.rand_like(z), torch.rand_like(y))
+        z_in, y_in = z + (uz - 0.5), y + (uy - 0.5)
+    else:
+        z_in, y_in = torch.round(z), torch.round(y)
+    psi = hyper_decoder(z_in, P, kind)
+    w = P["context_model.masked.weight"]
+    mask = torch.ones_like(w)
+    mask[:, :, 2, 2:] = 0
+    mask[:, :, 3:] = 0
+    with torch.no_grad():
+        w.mul_(mask)  # ContextModels.py:19 (in place, outside autograd)
+    phi = F.conv2d(y_in, w, P["context_model.masked.bias"], padding=2)
+    h = torch.cat([phi, psi], dim=1)
+    ep = "entropy_parameters.net."
+    h = _lrelu(_conv(h, P, ep + "0", 1, 0))
+    h = _lrelu(_conv(h, P, ep + "2", 1, 0))
+    raw = _conv(h, P, ep + "4", 1, 0)
+    out = {}
+    if K == 1:
+        mu, sg = raw.chunk(2, dim=1)
+        sg = F.softplus(sg) + 1e-6
+        p_y = _gcdf((y_in + 0.5 - mu) / sg) - _gcdf((y_in - 0.5 - mu) / sg)
+        out.update(mu=mu, sigma=sg)
+    else:
+        B, _, hh, ww = raw.shape
+        wt, mus, sgs = (t.reshape(B, K, M, hh, ww) for t in raw.chunk(3, dim=1))
+        wt = F.softmax(wt, dim=1)
+        sgs = F.softplus(sgs) + 1e-6
+        xe = y_in.unsqueeze(1)
+        p_y = (wt * (_gcdf((xe + 0.5 - mus) / sgs) - _gcdf((xe - 0.5 - mus) / sgs))).sum(dim=1)
+        out.update(weights=wt, mus=mus, sigmas=sgs)
+    p_y = p_y.clamp_min(1e-9)
+    p_z = _factorized(z_in, P).clamp_min(1e-9)
+    out.update(x_hat=decoder(y_in, P, kind), y=y, y_in=y_in, z=z, z_in=z_in, p_z=p_z,
+               logp_z=torch.log(p_z), p_y=p_y, logp_y=torch.log(p_y), training=training)
+    return out
+
+
+def rd_loss(out, x, lambda_rd):
+    """RateDistortionLoss.py:5-49 (tensor results, no .item())."""
+    npix = x.size(2) * x.size(3)
+    bits_y = -out["logp_y"].sum(dim=(1, 2, 3)) / math.log(2.0)
+    bits_z = -out["logp_z"].sum(dim=(1, 2, 3)) / math.log(2.0)
+    bpp_y, bpp_z = (bits_y / npix).mean(), (bits_z / npix).mean()
+    mse_img = ((out["x_hat"] - x) ** 2).mean(dim=(1, 2, 3))
+    mse = mse_img.mean()
+    return {"loss": bpp_y + bpp_z + lambda_rd * 255 ** 2 * mse, "bpp_y": bpp_y, "bpp_z": bpp_z,
+            "bpp_total": bpp_y + bpp_z, "mse": mse, "psnr": -10 * torch.log10(mse + 1e-8),
+            "bits_y": bits_y.mean(), "bits_z": bits_z.mean(), "mse_per_image": mse_img}
+
+
+def step(state: Dict[str, "object"], x, M, K, kind="5x5", noise=None, lambda_rd=0.01):
+    """One forward + rd_loss + backward on CPU; `state` values may be numpy arrays or tensors.
+    Returns (out, loss dict of floats, grads dict of numpy arrays)."""
+    import numpy as np
+    P = {}
+    for k, v in state.items():
+        t = torch.as_tensor(np.asarray(v)).clone() if not torch.is_tensor(v) else v.detach().clone().cpu()
+        if t.is_floating_point() and k.split(".")[-1] not in ("pedestal", "bound", "mask"):
+            t.requires_grad_(True)
+        P[k] = t
+    xt = torch.as_tensor(np.asarray(x)) if not torch.is_tensor(x) else x.cpu()
+    nz = None if noise is None else tuple(torch.as_tensor(np.asarray(n)) for n in noise)
+    out = forward(P, xt, M, K, kind, True, nz)
+    res = rd_loss(out, xt, lambda_rd)
+    res["loss"].backward()
+    grads = {k: v.grad.numpy() for k, v in P.items() if v.requires_grad and v.grad is not None}
+    loss = {k: float(v.detach()) for k, v in res.items() if v.dim() == 0}
+    return {k: (v.detach().numpy() if torch.is_tensor(v) else v) for k, v in out.items()}, loss, grads

@@ -205,3 +205,37 @@ def test_hmr_full_capacity_runs(env):
     res["loss"].backward()
     assert tuple(out["y"].shape) == (4, 192, 16, 16) and math.isfinite(float(res["loss"]))
     assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+@pytest.mark.parametrize("K", [1, 3])
+def test_full_capacity_batch_vs_torch_cpu_path(env, K):
+    """JAH(192, K) on 2x3x256x256: the HIP path against oracle/torch_ref.py (torch CPU ops, the
+    arithmetic the reference's own CPU path uses) -- latents, bpp, PSNR within 1e-4 relative
+    (north star) and every parameter gradient relative to its tensor's scale."""
+    nic, F_, O, dev = env
+    from oracle import torch_ref as TR
+    M, lam, B = 192, 0.01, 2
+    model = nic.JointAutoregressiveHierarchical(M, K)
+    ks = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    st = R.make_state(ks, 91 + K)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
+    model = model.to(dev)
+    x = R.make_image(B, 256, 256, 92)
+    uz, uy = R.make_noise((B, M, 4, 4), 93), R.make_noise((B, M, 16, 16), 94)
+    tx = torch.from_numpy(x).to(dev).contiguous(memory_format=torch.channels_last)
+    out = model(tx, noise=(torch.from_numpy(uz).to(dev), torch.from_numpy(uy).to(dev)))
+    res = nic.rd_loss(out, tx, lam)
+    res["loss"].backward()
+    t_out, t_loss, t_grads = TR.step(st, x, M, K, "5x5", (uz, uy), lam)
+    for k in ("y", "z", "x_hat"):
+        a, b = out[k].detach().cpu().numpy().astype(np.float64), t_out[k].astype(np.float64)
+        assert (np.abs(a - b) <= 1e-4 + 1e-4 * np.abs(b)).all(), (k, np.abs(a - b).max())
+    for k in ("bpp_y", "bpp_z", "bpp_total", "mse", "psnr"):
+        assert abs(res[k] - t_loss[k]) <= 1e-4 * abs(t_loss[k]), (k, res[k], t_loss[k])
+    worst = ("", 0.0)
+    for name, p in model.named_parameters():
+        ref = t_grads[name]
+        e = float(np.abs(p.grad.detach().cpu().numpy() - ref).max() / max(np.abs(ref).max(), 1e-12))
+        if e > worst[1]:
+            worst = (name, e)
+    assert worst[1] <= 5e-4, worst
