@@ -243,8 +243,8 @@ LIC_EXPORT int lic_gdn_reparam_bwd(const float* p, const float* dout, float* dp,
 }
 
 __device__ __forceinline__ float gdn_t1(float g, float x, float n, int inverse) {
-  const float rs = 1.0f / sqrtf(n);
-  return inverse ? 0.5f * g * x * rs : -0.5f * g * x * rs / n;
+  const float rs = __builtin_amdgcn_rsqf(n);  // v_rsq_f32, 1 ulp
+  return inverse ? 0.5f * g * x * rs : -0.5f * g * x * rs * (rs * rs);
 }
 LIC_EXPORT int lic_gdn_dnorm(const float* g, const float* x, const float* norm, float* t, int64_t n,
                              int32_t inverse, lic_stream_t stream) {

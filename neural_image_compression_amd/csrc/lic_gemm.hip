@@ -359,15 +359,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
               if (p.out2) *reinterpret_cast<f32x4*>(p.out2 + opix * p.out2_ld + col) = v;
               const f32x4 x = *reinterpret_cast<const f32x4*>(p.aux + opix * p.aux_ld + col);
 #pragma unroll
-              for (int e = 0; e < 4; ++e)
-                v[e] = x[e] * ((epi == LIC_EPI_GDN) ? 1.0f / sqrtf(v[e]) : sqrtf(v[e]));
+              for (int e = 0; e < 4; ++e)  // v_rsq_f32 / v_sqrt_f32: 1 ulp, far inside the 1e-4 bar
+                v[e] = x[e] * ((epi == LIC_EPI_GDN) ? __builtin_amdgcn_rsqf(v[e]) : __builtin_amdgcn_sqrtf(v[e]));
             } else if (epi == LIC_EPI_GDN_BWD || epi == LIC_EPI_IGDN_BWD) {
               const f32x4 n = *reinterpret_cast<const f32x4*>(p.aux3 + opix * p.aux3_ld + col);
               const f32x4 g = *reinterpret_cast<const f32x4*>(p.aux + opix * p.aux_ld + col);
               const f32x4 x = *reinterpret_cast<const f32x4*>(p.aux2 + opix * p.aux2_ld + col);
 #pragma unroll
               for (int e = 0; e < 4; ++e) {
-                const float f = (epi == LIC_EPI_GDN_BWD) ? 1.0f / sqrtf(n[e]) : sqrtf(n[e]);
+                const float f = (epi == LIC_EPI_GDN_BWD) ? __builtin_amdgcn_rsqf(n[e]) : __builtin_amdgcn_sqrtf(n[e]);
                 v[e] = g[e] * f + 2.0f * x[e] * v[e];
               }
             }
