@@ -97,11 +97,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X (no CPU fallback for the product path)")
+    # LIC_SINGLE_DEVICE=1 + LIC_DIST_BACKEND=gloo rehearse the N>1 code path on a one-GPU box
+    # (all ranks share cuda:0; RCCL itself needs one device per rank)
+    if os.environ.get("LIC_SINGLE_DEVICE") == "1":
+        local_rank = 0
+    backend = os.environ.get("LIC_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import neural_image_compression_amd as nic
     from neural_image_compression_amd import functional as F_
@@ -159,7 +167,7 @@ def main():
             "config": {"workload": f"cfg{args.config}: JointAutoregressiveHierarchical(M={M},K={K}) "
                                    f"fwd+rd_loss(lambda={lam})+bwd+Adam, {B}x3x{H}x{W} per GPU, fp32",
                        "global_batch": world * B, "parallelism": f"dp{world}",
-                       "loss": round(float(res["loss"]), 6)},
+                       "loss": round(float(res["loss"].detach()), 6)},
         }
         if prof:
             # per-kernel totals from HIP events recorded around every MFMA launch of the timed region
