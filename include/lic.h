@@ -86,7 +86,12 @@ typedef struct lic_igemm_desc {
   int32_t epilogue; /* enum lic_epilogue */
   uint32_t tap_mask; /* bit (r*kw+s) set = tap is live; 0 = all taps (kh*kw <= 32) */
   float slope;       /* LeakyReLU negative slope */
+  void* workspace;   /* optional (may be NULL): lets small layers split K across workgroups */
+  size_t workspace_bytes;
 } lic_igemm_desc;
+
+/* workspace size that enables split-K for `d` (0 = the layer is large enough not to need it) */
+size_t lic_igemm_workspace_bytes(const lic_igemm_desc* d);
 
 int lic_igemm(const lic_igemm_desc* d, lic_stream_t stream);
 /* Weight packing for lic_igemm.  Logical element (tap, k, n) is read from

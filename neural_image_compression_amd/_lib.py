@@ -27,7 +27,7 @@ class IgemmDesc(C.Structure):
                 ("Ho", _i32), ("Wo", _i32), ("Cout", _i32),
                 ("kh", _i32), ("kw", _i32), ("stride", _i32), ("pad", _i32),
                 ("transposed", _i32), ("prologue", _i32), ("epilogue", _i32),
-                ("tap_mask", C.c_uint32), ("slope", _f32)]
+                ("tap_mask", C.c_uint32), ("slope", _f32), ("workspace", _vp), ("workspace_bytes", _sz)]
 
 
 class WgradDesc(C.Structure):
@@ -43,6 +43,7 @@ class WgradDesc(C.Structure):
 # name -> (restype, argtypes); every symbol declared in include/lic.h
 SIGNATURES = {
     "lic_igemm": (C.c_int, [C.POINTER(IgemmDesc), _vp]),
+    "lic_igemm_workspace_bytes": (_sz, [C.POINTER(IgemmDesc)]),
     "lic_igemm_plan": (C.c_int, [C.POINTER(IgemmDesc), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i64)]),
     "lic_packed_weight_floats": (_i64, [_i32, _i32, _i32]),
     "lic_pack_weight": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _vp]),

@@ -109,7 +109,7 @@ LIC_EXPORT int lic_col2im(const float* col, const float* bias, float* out, int32
 // ---------------------------------------------------------------------------------------------
 // column sums (bias gradients): two deterministic stages
 // ---------------------------------------------------------------------------------------------
-#define CS_MAXCHUNK 512
+#define CS_MAXCHUNK 256
 // block = 16 column groups (float4 = 64 columns) x 16 row lanes; grid (ceil(C/64), nchunk)
 __global__ __launch_bounds__(256) void colsum_stage1(const float* in, long ld, long P, int C, float* part,
                                                      int nchunk, int vec) {
@@ -139,18 +139,23 @@ __global__ __launch_bounds__(256) void colsum_stage1(const float* in, long ld, l
     if (cc < C) part[(long)blockIdx.y * C + cc] = s;
   }
 }
-// block = 64 columns x 4 chunk lanes
+// block = 16 columns x 16 chunk lanes (short dependent chains: this stage is pure latency)
 __global__ __launch_bounds__(256) void colsum_stage2(const float* part, int C, int nchunk, float scale,
                                                      float* out) {
-  __shared__ double red[4][64];
-  const int cx = threadIdx.x & 63, ly = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cx;
+  __shared__ double red[16][17];
+  const int cx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cx;
   double acc = 0.0;
   if (c < C)
-    for (int y = ly; y < nchunk; y += 4) acc += (double)part[(long)y * C + c];
+    for (int y = ly; y < nchunk; y += 16) acc += (double)part[(long)y * C + c];
   red[ly][cx] = acc;
   __syncthreads();
-  if (ly == 0 && c < C) out[c] = (float)(((red[0][cx] + red[1][cx]) + (red[2][cx] + red[3][cx])) * (double)scale);
+  if (ly == 0 && c < C) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][cx];
+    out[c] = (float)(t * (double)scale);
+  }
 }
 static int colsum_chunks(int64_t P) {
   int64_t n = cdiv64(P, 16 * 8);
@@ -173,7 +178,7 @@ LIC_EXPORT int lic_colsum(const float* in, int64_t ld, int64_t P, int32_t C, flo
                      (float*)workspace, nchunk, vec);
   int rc = lic_check_launch();
   if (rc != LIC_OK) return rc;
-  hipLaunchKernelGGL(colsum_stage2, dim3((C + 63) / 64), dim3(256), 0, s, (const float*)workspace, C,
+  hipLaunchKernelGGL(colsum_stage2, dim3((C + 15) / 16), dim3(256), 0, s, (const float*)workspace, C,
                      nchunk, scale, out);
   return lic_check_launch();
 }

@@ -57,6 +57,9 @@ struct IgemmParams {
   int cpt;     // 16-deep chunks per tap
   int Npad;    // Cout rounded up to 32 (packed weight pitch)
   int nphase;  // 1, or stride^2 output phases of a transposed conv
+  int ksplit;  // >1: K (the chunk list) is split across workgroups; raw partial sums go to `slabs`
+  int cps;     // chunks per split
+  float* slabs;  // [ksplit][B*Ho*Wo][Cout] fp32
   int MT, NT;  // tiles in M (max over phases) and N
   int ntaps[4];
   int Hq[4], Wq[4];
@@ -99,6 +102,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   }
   // phases interleave under one M tile index so that every XCD's contiguous id range holds all
   // phases (their K lengths differ up to 2.25x: 9/6/6/4 taps for 5x5 stride 2)
+  const int ks = wg % p.ksplit;  // K split fastest: the splits of a tile share its A rows in L2
+  wg /= p.ksplit;
   const int nt = wg % p.NT;
   const int kq = wg / p.NT;
   // Rotate the phase order from one M tile to the next.  Phase durations differ (9/6/6/4 taps)
@@ -150,7 +155,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   for (int b = 0; b < TN; ++b) n_live += ((n0 + wn0 + b * 32) < p.Npad) ? 1 : 0;
 
   const int ntaps = p.ntaps[phase];
-  const int nchunks = ntaps * p.cpt;
+  const int c_first = ks * p.cps;  // this workgroup's slice of the (tap, channel-block) chunk list
+  const int nchunks = max(0, min(ntaps * p.cpt, c_first + p.cps) - c_first);
   f32x4 ra[APASS];
   bool ra_ok[APASS];
   // this lane's B-operand address inside a (tap, chunk) panel: column n, K-half lh
@@ -254,7 +260,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   };
 
   // chunk cursor for the loads (runs ahead of the compute cursor)
-  int l_tap = 0, l_cb = 0;
+  int l_tap = c_first / p.cpt, l_cb = c_first - l_tap * p.cpt;
   auto advance = [&]() {
     if (++l_cb == p.cpt) {
       l_cb = 0;
@@ -263,8 +269,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   };
   f32x4 rb0[TN][2], rb1[TN][2];
   if (nchunks > 0) {
-    load_a(0, 0);
-    load_b(rb0, 0, 0);
+    load_a(l_tap, l_cb);
+    load_b(rb0, l_tap, l_cb);
     store_a(0);
     __syncthreads();
     advance();  // cursor -> chunk 1
@@ -310,6 +316,29 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   }
 
   // ---- epilogue -------------------------------------------------------------------------------
+  if (p.ksplit > 1) {  // raw partial sums -> slab [ks][pixel][Cout]; igemm_finish_kernel does the rest
+    float* slab = p.slabs + (long)ks * ((long)p.B * p.Ho * p.Wo) * p.Cout;
+#pragma unroll
+    for (int a = 0; a < TM; ++a)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int prow = m0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (prow >= P) continue;
+        long opix = prow;
+        if (p.nphase > 1) {
+          const int b = fdiv(prow, p.dHW[phase]);
+          const int rem = prow - b * Hq * Wq;
+          const int i = fdiv(rem, p.dW[phase]), jj = rem - i * Wq;
+          opix = ((long)b * p.Ho + i * sph + py) * p.Wo + jj * sph + px;
+        }
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          const int col = n0 + wn0 + b * 32 + li;
+          if (col < p.Cout) slab[opix * p.Cout + col] = acc[a][b][r];
+        }
+      }
+    return;
+  }
   const int epi = p.epilogue;
   if (p.vec_out) {
     // Stage each 32x32 accumulator tile through LDS so that every lane owns 4 consecutive
@@ -454,6 +483,22 @@ LIC_EXPORT int lic_pack_weight(const float* src, float* dst, int32_t taps, int32
   return lic_check_launch();
 }
 
+// split-K finish: out = epilogue(sum_s slab[s] + bias) for the NONE / LEAKY epilogues
+__global__ __launch_bounds__(256) void igemm_finish_kernel(const float* slabs, int ksplit, long npix, int Cout,
+                                                           const float* bias, float* out, long out_ld,
+                                                           int leaky, float slope) {
+  const long total = npix * Cout;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long pix = i / Cout;
+    const int c = (int)(i - pix * Cout);
+    float v = 0.0f;
+    for (int s = 0; s < ksplit; ++s) v += slabs[(long)s * total + i];
+    if (bias) v += bias[c];
+    if (leaky) v = v > 0.0f ? v : v * slope;
+    out[pix * out_ld + c] = v;
+  }
+}
+
 // fills the kernel parameter block; returns LIC_OK, or 1 when there is nothing to launch
 static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& TN, long& nwg,
                          int64_t& live_macs) {
@@ -576,8 +621,51 @@ static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& 
   p.NT = (p.Npad + 64 * TN - 1) / (64 * TN);
   p.MT = (int)((maxP + BM - 1) / BM);
   nwg = (long)p.MT * p.NT * p.nphase;
+  // Small layers (the 16x16 / 8x8 / 4x4 latent side) cannot fill 256 CUs with output tiles alone:
+  // split their K loop across workgroups when the caller provided a workspace.
+  p.ksplit = 1;
+  p.slabs = nullptr;
+  int max_chunks = 0;
+  for (int ph = 0; ph < p.nphase; ++ph) max_chunks = p.ntaps[ph] * p.cpt > max_chunks ? p.ntaps[ph] * p.cpt : max_chunks;
+  p.cps = max_chunks > 0 ? max_chunks : 1;
+  const bool simple_epi = (epi == LIC_EPI_NONE || epi == LIC_EPI_LEAKY) && !d->res && !d->out2;
+  // The split factor depends only on per-image geometry (never on the batch size), so an image's
+  // result does not depend on which batch it is computed in (bitwise batch-split invariance).
+  const long t_img = (((long)d->Ho * d->Wo + 63) / 64) * ((p.Npad + 63) / 64);
+  if (simple_epi && d->workspace && t_img < 40 && max_chunks >= 16) {
+    long S = (40 + t_img - 1) / t_img;
+    if (S > max_chunks / 8) S = max_chunks / 8;  // at least 8 chunks per split
+    if (S > 32) S = 32;
+    if (S > 1) {
+      p.cps = (int)((max_chunks + S - 1) / S);
+      p.ksplit = (max_chunks + p.cps - 1) / p.cps;
+      const size_t need = (size_t)p.ksplit * d->B * d->Ho * d->Wo * d->Cout * sizeof(float);
+      if (d->workspace_bytes < need) return LIC_ERR_WORKSPACE;
+      p.slabs = (float*)d->workspace;
+      nwg *= p.ksplit;
+    }
+  }
   if (nwg > 0x7FFFFFFFL) return LIC_ERR_UNSUPPORTED;
   return LIC_OK;
+}
+
+LIC_EXPORT size_t lic_igemm_workspace_bytes(const lic_igemm_desc* d) {
+  if (!d) return 0;
+  lic_igemm_desc q = *d;  // plan with stand-in pointers and an unlimited workspace
+  static float dummy[4] __attribute__((aligned(16)));
+  q.in = q.w = dummy;
+  q.out = dummy;
+  q.bias = q.aux = q.aux2 = q.aux3 = q.res = nullptr;
+  q.out2 = nullptr;
+  if (q.epilogue != LIC_EPI_NONE && q.epilogue != LIC_EPI_LEAKY) return 0;
+  q.workspace = dummy;
+  q.workspace_bytes = ~(size_t)0;
+  IgemmParams p;
+  int bm = 0, tn = 0;
+  long nwg = 0;
+  int64_t macs = 0;
+  if (igemm_prepare(&q, p, bm, tn, nwg, macs) != LIC_OK || p.ksplit <= 1) return 0;
+  return (size_t)p.ksplit * d->B * d->Ho * d->Wo * d->Cout * sizeof(float);
 }
 
 LIC_EXPORT int lic_igemm_plan(const lic_igemm_desc* d, int32_t* BM, int32_t* BN, int64_t* live_macs) {
@@ -626,6 +714,14 @@ LIC_EXPORT int lic_igemm(const lic_igemm_desc* d, lic_stream_t stream) {
   else
     LIC_IGEMM_LAUNCH(64, 1);
 #undef LIC_IGEMM_LAUNCH
+  if (p.ksplit > 1) {
+    int rc2 = lic_check_launch();
+    if (rc2 != LIC_OK) return rc2;
+    const long npix = (long)d->B * d->Ho * d->Wo;
+    hipLaunchKernelGGL(igemm_finish_kernel, dim3(ew_grid(npix * d->Cout, 256)), dim3(256), 0, s,
+                       (const float*)p.slabs, p.ksplit, npix, d->Cout, d->bias, d->out, (long)d->out_ld,
+                       d->epilogue == LIC_EPI_LEAKY ? 1 : 0, d->slope);
+  }
   return lic_check_launch();
 }
 

@@ -106,6 +106,12 @@ def _igemm(inp, w_packed, out, *, B, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, 
     d.transposed, d.prologue, d.epilogue = int(transposed), prologue, epilogue
     d.tap_mask, d.slope = tap_mask, slope
     lib = L.load()
+    ws = None
+    if Ho * Wo <= 1024 and out2 is None and res is None:  # latent-side layers: allow split-K
+        nbytes = lib.lic_igemm_workspace_bytes(C.byref(d))
+        if nbytes:
+            ws = torch.empty(nbytes // 4, device=inp.device, dtype=torch.float32)
+            d.workspace, d.workspace_bytes = _ptr(ws), nbytes
     if PROFILE is None:
         L.check(lib.lic_igemm(C.byref(d), _stream()), "lic_igemm")
         return
