@@ -593,6 +593,8 @@ static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& 
   // Tile selection.  Dead 32-column tiles are skipped by the waves, so every BN wastes the same
   // MFMA work; prefer the widest N tile (activations are gathered once per N tile) as long as
   // the grid keeps >= 512 workgroups, else fall back towards small tiles for parallelism.
+  int max_taps = 0;
+  for (int ph = 0; ph < p.nphase; ++ph) max_taps = p.ntaps[ph] > max_taps ? p.ntaps[ph] : max_taps;
   static const int cand[6][2] = {{128, 3}, {64, 3}, {128, 2}, {64, 2}, {128, 1}, {64, 1}};
   int best = 5;
   long best_wg = -1;
@@ -602,6 +604,9 @@ static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& 
     for (int c = 0; c < 6; ++c) {
       const int bm = cand[c][0], tn = cand[c][1];
       if (!p.vec && !(bm == 64 && tn == 1)) continue;  // scalar-A variant exists for one shape only
+      // short-K layers (GDN contraction, 1x1 convs: <= 16 chunks) spend most of a workgroup's life
+      // in prologue + epilogue: smaller M tiles put more workgroups in flight to overlap them
+      if (bm == 128 && max_taps * p.cpt <= 16) continue;
       if (p.Npad < 64 * tn && tn > 1 && p.Npad <= 64 * (tn - 1)) continue;  // wider than the problem
       if (pass == 0 && p.Npad % (64 * tn) != 0) continue;
       const long wgs = ((maxP + bm - 1) / bm) * ((p.Npad + 64 * tn - 1) / (64 * tn)) * p.nphase;
