@@ -213,6 +213,31 @@ int lic_rd_loss_bwd(const float* x_hat, const float* x, int64_t ny, int64_t nz, 
                     int32_t B, int64_t num_pixels, float lambda_rd, const float* gl, float* dlogp_y,
                     float* dlogp_z, float* dx_hat, lic_stream_t stream);
 
+/* ---- bf16-storage variants (BASELINE config 3) --------------------------------------------------
+ * Activations / auxiliaries are bf16 NHWC (pitches and channel counts multiples of 8), weights are
+ * packed to bf16 by lic_pack_weight_bf16 ([tap][ceil(K/32)][ceil32(N)][32]), bias and all
+ * accumulation are fp32 (v_mfma_f32_32x32x16_bf16).  lic_igemm_bf16 supports the NONE / GDN / IGDN
+ * / GDN_BWD / IGDN_BWD epilogues (no residual); `out` is bf16, or fp32 when out_f32 != 0.
+ * Parameter gradients (lic_wgrad_bf16 dst, lic_colsum_bf16 out) are fp32. */
+int64_t lic_packed_weight_bf16_elems(int32_t taps, int32_t K, int32_t N);
+int lic_pack_weight_bf16(const float* src, void* dst, int32_t taps, int32_t K, int32_t N, int64_t s_tap,
+                         int64_t s_k, int64_t s_n, lic_stream_t stream);
+int lic_igemm_bf16(const lic_igemm_desc* d, int32_t out_f32, lic_stream_t stream);
+size_t lic_wgrad_bf16_workspace_bytes(const lic_wgrad_desc* d);
+int lic_wgrad_bf16(const lic_wgrad_desc* d, void* workspace, size_t workspace_bytes, lic_stream_t stream);
+/* fp32 image -> bf16 columns; bf16 columns -> fp32 image (+ fp32 bias) */
+int lic_im2col_bf16(const float* x, void* col, int32_t B, int32_t H, int32_t W, int32_t C, int32_t Ho,
+                    int32_t Wo, int32_t kh, int32_t kw, int32_t stride, int32_t pad, int32_t Kpad,
+                    lic_stream_t stream);
+int lic_col2im_bf16(const void* col, const float* bias, float* out, int32_t B, int32_t Hi, int32_t Wi,
+                    int32_t C, int32_t Ho, int32_t Wo, int32_t kh, int32_t kw, int32_t stride, int32_t pad,
+                    int32_t Kpad, lic_stream_t stream);
+size_t lic_colsum_bf16_workspace_bytes(int64_t P, int32_t C);
+int lic_colsum_bf16(const void* in, int64_t ld, int64_t P, int32_t C, float scale, float* out,
+                    void* workspace, size_t workspace_bytes, lic_stream_t stream);
+int lic_gdn_dnorm_bf16(const void* g, const void* x, const void* norm, void* t, int64_t n, int32_t inverse,
+                       lic_stream_t stream);
+
 /* ---- misc ---------------------------------------------------------------------------------- */
 int lic_version(void);        /* LIC_ABI_VERSION */
 int lic_last_hip_error(void); /* hipError_t of the most recent failed launch on this thread */

@@ -71,6 +71,16 @@ SIGNATURES = {
     "lic_rd_loss_workspace_bytes": (_sz, [_i32]),
     "lic_rd_loss_fwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i64, _f32, _vp, _vp, _sz, _vp]),
     "lic_rd_loss_bwd": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i32, _i64, _f32, _vp, _vp, _vp, _vp, _vp]),
+    "lic_packed_weight_bf16_elems": (_i64, [_i32, _i32, _i32]),
+    "lic_pack_weight_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _vp]),
+    "lic_igemm_bf16": (C.c_int, [C.POINTER(IgemmDesc), _i32, _vp]),
+    "lic_wgrad_bf16_workspace_bytes": (_sz, [C.POINTER(WgradDesc)]),
+    "lic_wgrad_bf16": (C.c_int, [C.POINTER(WgradDesc), _vp, _sz, _vp]),
+    "lic_im2col_bf16": (C.c_int, [_vp, _vp] + [_i32] * 11 + [_vp]),
+    "lic_col2im_bf16": (C.c_int, [_vp, _vp, _vp] + [_i32] * 11 + [_vp]),
+    "lic_colsum_bf16_workspace_bytes": (_sz, [_i64, _i32]),
+    "lic_colsum_bf16": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _vp, _vp, _sz, _vp]),
+    "lic_gdn_dnorm_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "lic_version": (C.c_int, []),
     "lic_last_hip_error": (C.c_int, []),
     "lic_arch": (C.c_char_p, []),

@@ -7,11 +7,15 @@ from __future__ import annotations
 import torch.nn as nn
 
 from .layers import (Conv2d, ConvTranspose2d, GDN, LeakyReLU, ResidualBlock, ResidualBlockUpsample,
-                     ResidualBlockWithStride, TransposedDeconv3x3, run_fused)
+                     ResidualBlockWithStride, TransposedDeconv3x3, run_bf16, run_fused)
 
 
 class _Stack(nn.Module):
+    precision = "fp32"  # "bf16": bf16 activations between the layers (5x5 conv/GDN stacks only)
+
     def forward(self, x):
+        if self.precision == "bf16":
+            return run_bf16(self.net, x)
         return run_fused(self.net, x)
 
 

@@ -1,0 +1,174 @@
+// HBM-bound helpers of the bf16-storage path (BASELINE config 3): patch<->column conversion
+// with bf16 columns, column sums and the GDN dL/dnorm map on bf16 tensors.  fp32 arithmetic inside.
+#include "lic_common.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// col[(b,oh,ow)][(r*kw+s)*C + c] (bf16) = x[b, oh*stride-pad+r, ow*stride-pad+s, c] (fp32), 0 outside / pad
+__global__ __launch_bounds__(256) void im2col_bf16_kernel(const float* x, bf16_t* col, int B, int H, int W, int C,
+                                                          int Ho, int Wo, int kh, int kw, int stride, int pad,
+                                                          int Kpad) {
+  const long total = (long)B * Ho * Wo * Kpad;
+  const int K = kh * kw * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int k = (int)(i % Kpad);
+    const long pix = i / Kpad;
+    float v = 0.0f;
+    if (k < K) {
+      const int c = k % C, tap = k / C;
+      const int r = tap / kw, s = tap - r * kw;
+      const int ow = (int)(pix % Wo);
+      const long t = pix / Wo;
+      const int oh = (int)(t % Ho);
+      const int b = (int)(t / Ho);
+      const int ih = oh * stride - pad + r, iw = ow * stride - pad + s;
+      if (ih >= 0 && iw >= 0 && ih < H && iw < W) v = x[(((long)b * H + ih) * W + iw) * C + c];
+    }
+    col[i] = (bf16_t)v;
+  }
+}
+LIC_EXPORT int lic_im2col_bf16(const float* x, void* col, int32_t B, int32_t H, int32_t W, int32_t C, int32_t Ho,
+                               int32_t Wo, int32_t kh, int32_t kw, int32_t stride, int32_t pad, int32_t Kpad,
+                               lic_stream_t stream) {
+  if (!x || !col || B <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || Kpad < kh * kw * C)
+    return LIC_ERR_INVALID;
+  const long total = (long)B * Ho * Wo * Kpad;
+  hipLaunchKernelGGL(im2col_bf16_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                     (bf16_t*)col, B, H, W, C, Ho, Wo, kh, kw, stride, pad, Kpad);
+  return lic_check_launch();
+}
+
+// out[b,oy,ox,c] (fp32) = bias[c] + sum_{r,s} col[(b,ih,iw)][(r*kw+s)*C + c] (bf16), oy = ih*stride-pad+r
+__global__ __launch_bounds__(256) void col2im_bf16_kernel(const bf16_t* col, const float* bias, float* out, int B,
+                                                          int Hi, int Wi, int C, int Ho, int Wo, int kh, int kw,
+                                                          int stride, int pad, int Kpad) {
+  const long total = (long)B * Ho * Wo * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const long pix = i / C;
+    const int ox = (int)(pix % Wo);
+    const long t = pix / Wo;
+    const int oy = (int)(t % Ho);
+    const int b = (int)(t / Ho);
+    float v = bias ? bias[c] : 0.0f;
+    for (int r = 0; r < kh; ++r) {
+      const int nh = oy + pad - r;
+      if (nh < 0 || (nh % stride) != 0) continue;
+      const int ih = nh / stride;
+      if (ih >= Hi) continue;
+      for (int s = 0; s < kw; ++s) {
+        const int nw = ox + pad - s;
+        if (nw < 0 || (nw % stride) != 0) continue;
+        const int iw = nw / stride;
+        if (iw >= Wi) continue;
+        v += (float)col[(((long)b * Hi + ih) * Wi + iw) * Kpad + (r * kw + s) * C + c];
+      }
+    }
+    out[i] = v;
+  }
+}
+LIC_EXPORT int lic_col2im_bf16(const void* col, const float* bias, float* out, int32_t B, int32_t Hi, int32_t Wi,
+                               int32_t C, int32_t Ho, int32_t Wo, int32_t kh, int32_t kw, int32_t stride,
+                               int32_t pad, int32_t Kpad, lic_stream_t stream) {
+  if (!col || !out || B <= 0 || Hi <= 0 || Wi <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || stride < 1 ||
+      Kpad < kh * kw * C)
+    return LIC_ERR_INVALID;
+  const long total = (long)B * Ho * Wo * C;
+  hipLaunchKernelGGL(col2im_bf16_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)col, bias, out, B, Hi, Wi, C, Ho, Wo, kh, kw, stride, pad, Kpad);
+  return lic_check_launch();
+}
+
+// column sums of a bf16 [P][ld] matrix -> fp32, two deterministic stages (C % 8 == 0)
+__global__ __launch_bounds__(256) void colsum_bf16_stage1(const bf16_t* in, long ld, long P, int C, float* part,
+                                                          int nchunk) {
+  __shared__ float red[32][64 + 4];
+  const int cg = threadIdx.x & 7, ry = threadIdx.x >> 3;  // 8 column octets x 32 row lanes
+  const int c = blockIdx.x * 64 + cg * 8;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (c < C)
+    for (long pr = (long)blockIdx.y * 32 + ry; pr < P; pr += (long)nchunk * 32) {
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(in + pr * ld + c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+    }
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[ry][cg * 8 + e] = acc[e];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int cc = blockIdx.x * 64 + threadIdx.x;
+    float s = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 32; ++r) s += red[r][threadIdx.x];
+    if (cc < C) part[(long)blockIdx.y * C + cc] = s;
+  }
+}
+__global__ __launch_bounds__(256) void colsum_bf16_stage2(const float* part, int C, int nchunk, float scale,
+                                                          float* out) {
+  __shared__ double red[16][17];
+  const int cx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cx;
+  double acc = 0.0;
+  if (c < C)
+    for (int y = ly; y < nchunk; y += 16) acc += (double)part[(long)y * C + c];
+  red[ly][cx] = acc;
+  __syncthreads();
+  if (ly == 0 && c < C) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += red[q][cx];
+    out[c] = (float)(t * (double)scale);
+  }
+}
+static int csh_chunks(int64_t P) {
+  int64_t n = cdiv64(P, 32 * 8);
+  if (n > 256) n = 256;
+  if (n < 1) n = 1;
+  return (int)n;
+}
+LIC_EXPORT size_t lic_colsum_bf16_workspace_bytes(int64_t P, int32_t C) {
+  if (P <= 0 || C <= 0) return 0;
+  return (size_t)csh_chunks(P) * C * sizeof(float);
+}
+LIC_EXPORT int lic_colsum_bf16(const void* in, int64_t ld, int64_t P, int32_t C, float scale, float* out,
+                               void* workspace, size_t workspace_bytes, lic_stream_t stream) {
+  if (!in || !out || !workspace || P <= 0 || C <= 0) return LIC_ERR_INVALID;
+  if (C % 8 || ld % 8 || (reinterpret_cast<uintptr_t>(in) & 15)) return LIC_ERR_UNSUPPORTED;
+  const int nchunk = csh_chunks(P);
+  if (workspace_bytes < (size_t)nchunk * C * sizeof(float)) return LIC_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(colsum_bf16_stage1, dim3((C + 63) / 64, nchunk), dim3(256), 0, s, (const bf16_t*)in, (long)ld,
+                     (long)P, C, (float*)workspace, nchunk);
+  int rc = lic_check_launch();
+  if (rc != LIC_OK) return rc;
+  hipLaunchKernelGGL(colsum_bf16_stage2, dim3((C + 15) / 16), dim3(256), 0, s, (const float*)workspace, C, nchunk,
+                     scale, out);
+  return lic_check_launch();
+}
+
+// t = dL/dnorm on bf16 tensors (n elements, n % 8 == 0): inverse ? 0.5*g*x*rsqrt(n) : -0.5*g*x*n^-3/2
+__global__ __launch_bounds__(256) void gdn_dnorm_bf16_kernel(const bf16_t* g, const bf16_t* x, const bf16_t* nrm,
+                                                             bf16_t* t, long n8, int inverse) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const bf16x8 gv = reinterpret_cast<const bf16x8*>(g)[i], xv = reinterpret_cast<const bf16x8*>(x)[i],
+                 nv = reinterpret_cast<const bf16x8*>(nrm)[i];
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float rs = __builtin_amdgcn_rsqf((float)nv[e]);
+      const float gx = (float)gv[e] * (float)xv[e];
+      o[e] = (bf16_t)(inverse ? 0.5f * gx * rs : -0.5f * gx * rs * (rs * rs));
+    }
+    reinterpret_cast<bf16x8*>(t)[i] = o;
+  }
+}
+LIC_EXPORT int lic_gdn_dnorm_bf16(const void* g, const void* x, const void* norm, void* t, int64_t n,
+                                  int32_t inverse, lic_stream_t stream) {
+  if (!g || !x || !norm || !t || n < 0) return LIC_ERR_INVALID;
+  if (n % 8) return LIC_ERR_UNSUPPORTED;
+  if (n == 0) return LIC_OK;
+  hipLaunchKernelGGL(gdn_dnorm_bf16_kernel, dim3(ew_grid(n / 8, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)g, (const bf16_t*)x, (const bf16_t*)norm, (bf16_t*)t, (long)(n / 8), inverse);
+  return lic_check_launch();
+}

@@ -1,0 +1,318 @@
+"""bf16-storage variants of the conv / GDN autograd Functions (BASELINE config 3).
+
+Activations between the layers of the analysis / synthesis stacks are bf16 (NHWC), parameters stay
+fp32 (the state dict is unchanged) and are packed to bf16 per call, every accumulation and every
+parameter gradient is fp32.  The latent side (y, z, hyper path, entropy parameters, likelihoods,
+rd_loss) stays fp32: the first layer of a stack casts its input, the last one writes fp32.
+No CPU fallback, same rules as functional.py.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from .functional import (PEDESTAL, _colsum, _nchw_view, _nhwc, _permute3, _ptr, _stream, conv_out_size)
+
+BF16 = torch.bfloat16
+
+
+def _check(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise L.LicError("neural_image_compression_amd runs on MI355X only: got a non-CUDA tensor "
+                             "(there is no CPU fallback)")
+
+
+def _as_bf16_nhwc(t: torch.Tensor) -> torch.Tensor:
+    th = _nhwc(t)
+    return th if th.dtype == BF16 else th.to(BF16)
+
+
+def _pack_bf16(src: torch.Tensor, taps, K, N, s_tap, s_k, s_n) -> torch.Tensor:
+    lib = L.load()
+    out = torch.empty((lib.lic_packed_weight_bf16_elems(taps, K, N),), device=src.device, dtype=BF16)
+    L.check(lib.lic_pack_weight_bf16(_ptr(src), _ptr(out), taps, K, N, s_tap, s_k, s_n, _stream()),
+            "lic_pack_weight_bf16")
+    return out
+
+
+def _pack_conv_weight_bf16(w, transposed_weight, for_dgrad):
+    w = w.contiguous()
+    d0, d1, kh, kw = w.shape
+    taps = kh * kw
+    if transposed_weight:
+        cin, cout, s_ci, s_co = d0, d1, d1 * taps, taps
+    else:
+        cout, cin, s_co, s_ci = d0, d1, d1 * taps, taps
+    if for_dgrad:
+        return _pack_bf16(w, taps, cout, cin, 1, s_co, s_ci)
+    return _pack_bf16(w, taps, cin, cout, 1, s_ci, s_co)
+
+
+def _igemm_bf16(inp, w_packed, out, *, B, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, pad, transposed, bias=None,
+                prologue=0, epilogue=L.EPI_NONE, out2=None, aux=None, aux2=None, aux3=None):
+    d = L.IgemmDesc()
+    d.in_, d.w, d.bias, d.out, d.out2 = _ptr(inp), _ptr(w_packed), _ptr(bias), _ptr(out), _ptr(out2)
+    d.aux, d.aux2, d.aux3, d.res = _ptr(aux), _ptr(aux2), _ptr(aux3), None
+    d.in_ld, d.out_ld = Cin, Cout
+    d.out2_ld = d.aux_ld = d.aux2_ld = d.aux3_ld = d.res_ld = Cout
+    d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout = B, Hi, Wi, Cin, Ho, Wo, Cout
+    d.kh, d.kw, d.stride, d.pad = kh, kw, stride, pad
+    d.transposed, d.prologue, d.epilogue = int(transposed), prologue, epilogue
+    d.tap_mask, d.slope = 0, 0.01
+    L.check(L.load().lic_igemm_bf16(C.byref(d), int(out.dtype == torch.float32), _stream()), "lic_igemm_bf16")
+
+
+def _wgrad_bf16(p, g, dst, *, B, Hs, Ws, Cp, Hl, Wl, Cg, kh, kw, stride, pad, g_is_row, dst_sm, dst_sn, dst_stap,
+                sq_g=0):
+    d = L.WgradDesc()
+    d.p, d.g, d.dst = _ptr(p), _ptr(g), _ptr(dst)
+    d.p_ld, d.g_ld = Cp, Cg
+    d.dst_sm, d.dst_sn, d.dst_stap = dst_sm, dst_sn, dst_stap
+    d.B, d.Hs, d.Ws, d.Cp, d.Hl, d.Wl, d.Cg = B, Hs, Ws, Cp, Hl, Wl, Cg
+    d.kh, d.kw, d.stride, d.pad = kh, kw, stride, pad
+    d.g_is_row, d.sq_p, d.sq_g, d.scale = int(g_is_row), 0, sq_g, 1.0
+    lib = L.load()
+    nbytes = lib.lic_wgrad_bf16_workspace_bytes(C.byref(d))
+    ws = torch.empty((max(nbytes, 4) + 3) // 4, device=p.device, dtype=torch.float32)
+    L.check(lib.lic_wgrad_bf16(C.byref(d), _ptr(ws), nbytes, _stream()), "lic_wgrad_bf16")
+
+
+def _colsum_bf16(t2d, P, Cc):
+    lib = L.load()
+    nbytes = lib.lic_colsum_bf16_workspace_bytes(P, Cc)
+    ws = torch.empty((nbytes + 3) // 4, device=t2d.device, dtype=torch.float32)
+    out = torch.empty((Cc,), device=t2d.device, dtype=torch.float32)
+    L.check(lib.lic_colsum_bf16(_ptr(t2d), Cc, P, Cc, 1.0, _ptr(out), _ptr(ws), nbytes, _stream()),
+            "lic_colsum_bf16")
+    return out
+
+
+class _ConvBF16Fn(torch.autograd.Function):
+    """nn.Conv2d / nn.ConvTranspose2d with bf16 activations (Components.py:12-16,39-43)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, out_pad, transposed, out_f32):
+        _check(x, weight, bias)
+        xh = _as_bf16_nhwc(x)
+        B, Hi, Wi, Cin = xh.shape
+        kh, kw = weight.shape[2], weight.shape[3]
+        Cout = weight.shape[1] if transposed else weight.shape[0]
+        Ho, Wo = conv_out_size(Hi, Wi, kh, stride, pad, transposed, out_pad)
+        wp = _pack_conv_weight_bf16(weight, transposed, False)
+        out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32 if out_f32 else BF16)
+        _igemm_bf16(xh, wp, out, B=B, Hi=Hi, Wi=Wi, Cin=Cin, Ho=Ho, Wo=Wo, Cout=Cout, kh=kh, kw=kw, stride=stride,
+                    pad=pad, transposed=transposed, bias=bias)
+        ctx.save_for_backward(xh, weight)
+        ctx.cfg = (stride, pad, transposed, bias is not None, x.dtype)
+        return _nchw_view(out)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xh, weight = ctx.saved_tensors
+        stride, pad, transposed, has_bias, in_dtype = ctx.cfg
+        g = _as_bf16_nhwc(gy)
+        B, Hi, Wi, Cin = xh.shape
+        _, Ho, Wo, Cout = g.shape
+        kh, kw = weight.shape[2], weight.shape[3]
+        taps = kh * kw
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wp = _pack_conv_weight_bf16(weight, transposed, True)
+            dxh = torch.empty((B, Hi, Wi, Cin), device=g.device, dtype=in_dtype)
+            _igemm_bf16(g, wp, dxh, B=B, Hi=Ho, Wi=Wo, Cin=Cout, Ho=Hi, Wo=Wi, Cout=Cin, kh=kh, kw=kw, stride=stride,
+                        pad=pad, transposed=not transposed)
+            dx = _nchw_view(dxh)
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+            if transposed:
+                _wgrad_bf16(xh, g, dw, B=B, Hs=Hi, Ws=Wi, Cp=Cin, Hl=Ho, Wl=Wo, Cg=Cout, kh=kh, kw=kw, stride=stride,
+                            pad=pad, g_is_row=False, dst_sm=Cout * taps, dst_sn=taps, dst_stap=1)
+            else:
+                _wgrad_bf16(g, xh, dw, B=B, Hs=Ho, Ws=Wo, Cp=Cout, Hl=Hi, Wl=Wi, Cg=Cin, kh=kh, kw=kw, stride=stride,
+                            pad=pad, g_is_row=True, dst_sm=taps, dst_sn=Cin * taps, dst_stap=1)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = _colsum_bf16(g, B * Ho * Wo, Cout)
+        return dx, dw, db, None, None, None, None, None
+
+
+def _kpad8(kh, kw, c):
+    return (kh * kw * c + 7) // 8 * 8
+
+
+class _ImageConvBF16Fn(torch.autograd.Function):
+    """RGB stem (Components.py:10): fp32 image -> bf16 columns -> bf16 MFMA GEMM -> bf16 activations."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad):
+        _check(x, weight, bias)
+        if x.requires_grad:
+            raise NotImplementedError("the bf16 stem does not produce a gradient for the image")
+        xh = _nhwc(x).float()
+        B, Hi, Wi, Cin = xh.shape
+        Cout, _, kh, kw = weight.shape
+        Ho, Wo = conv_out_size(Hi, Wi, kh, stride, pad, False)
+        Kp, P, taps = _kpad8(kh, kw, Cin), B * Ho * Wo, kh * kw
+        lib = L.load()
+        col = torch.empty((P, Kp), device=x.device, dtype=BF16)
+        L.check(lib.lic_im2col_bf16(_ptr(xh), _ptr(col), B, Hi, Wi, Cin, Ho, Wo, kh, kw, stride, pad, Kp, _stream()),
+                "lic_im2col_bf16")
+        wd = torch.zeros((Kp, Cout), device=x.device, dtype=torch.float32)
+        _permute3(weight.contiguous(), wd, (taps, Cin, Cout), (1, taps, Cin * taps), (Cin * Cout, Cout, 1))
+        out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=BF16)
+        _igemm_bf16(col, _pack_bf16(wd, 1, Kp, Cout, 0, Cout, 1), out, B=1, Hi=1, Wi=P, Cin=Kp, Ho=1, Wo=P, Cout=Cout,
+                    kh=1, kw=1, stride=1, pad=0, transposed=False, bias=bias)
+        ctx.save_for_backward(col, weight)
+        ctx.cfg = (Cin, bias is not None)
+        return _nchw_view(out)
+
+    @staticmethod
+    def backward(ctx, gy):
+        col, weight = ctx.saved_tensors
+        Cin, has_bias = ctx.cfg
+        g = _as_bf16_nhwc(gy)
+        B, Ho, Wo, Cout = g.shape
+        _, _, kh, kw = weight.shape
+        taps, Kp, P = kh * kw, col.shape[1], B * Ho * Wo
+        dw = db = None
+        if ctx.needs_input_grad[1]:
+            tmp = torch.empty((Kp, Cout), device=g.device, dtype=torch.float32)
+            _wgrad_bf16(col, g, tmp, B=1, Hs=1, Ws=P, Cp=Kp, Hl=1, Wl=P, Cg=Cout, kh=1, kw=1, stride=1, pad=0,
+                        g_is_row=False, dst_sm=Cout, dst_sn=1, dst_stap=0)
+            dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+            _permute3(tmp, dw, (taps, Cin, Cout), (Cin * Cout, Cout, 1), (1, taps, Cin * taps))
+        if has_bias and ctx.needs_input_grad[2]:
+            db = _colsum_bf16(g, P, Cout)
+        return None, dw, db, None, None
+
+
+class _ImageConvTBF16Fn(torch.autograd.Function):
+    """RGB head (Components.py:45): bf16 activations -> bf16 per-tap columns -> fp32 image."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, out_pad):
+        _check(x, weight, bias)
+        xh = _as_bf16_nhwc(x)
+        B, Hi, Wi, Cin = xh.shape
+        _, Cout, kh, kw = weight.shape
+        Ho, Wo = conv_out_size(Hi, Wi, kh, stride, pad, True, out_pad)
+        taps, Kp, P = kh * kw, _kpad8(kh, kw, Cout), B * Hi * Wi
+        lib = L.load()
+        wd = torch.zeros((Cin, Kp), device=x.device, dtype=torch.float32)
+        _permute3(weight.contiguous(), wd, (Cin, Cout, taps), (Cout * taps, taps, 1), (Kp, 1, Cout))
+        col = torch.empty((P, Kp), device=x.device, dtype=BF16)
+        _igemm_bf16(xh, _pack_bf16(wd, 1, Cin, Kp, 0, Kp, 1), col, B=1, Hi=1, Wi=P, Cin=Cin, Ho=1, Wo=P, Cout=Kp,
+                    kh=1, kw=1, stride=1, pad=0, transposed=False)
+        out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+        L.check(lib.lic_col2im_bf16(_ptr(col), _ptr(bias), _ptr(out), B, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, pad,
+                                    Kp, _stream()), "lic_col2im_bf16")
+        ctx.save_for_backward(xh, weight)
+        ctx.cfg = (stride, pad, (Ho, Wo), bias is not None, x.dtype)
+        return _nchw_view(out)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xh, weight = ctx.saved_tensors
+        stride, pad, (Ho, Wo), has_bias, in_dtype = ctx.cfg
+        g = _nhwc(gy).float()
+        B, Hi, Wi, Cin = xh.shape
+        _, Cout, kh, kw = weight.shape
+        taps, Kp, P = kh * kw, _kpad8(kh, kw, Cout), B * Hi * Wi
+        lib = L.load()
+        dcol = torch.empty((P, Kp), device=g.device, dtype=BF16)
+        L.check(lib.lic_im2col_bf16(_ptr(g), _ptr(dcol), B, Ho, Wo, Cout, Hi, Wi, kh, kw, stride, pad, Kp, _stream()),
+                "lic_im2col_bf16")
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            wdT = torch.zeros((Kp, Cin), device=g.device, dtype=torch.float32)
+            _permute3(weight.contiguous(), wdT, (taps, Cout, Cin), (1, taps, Cout * taps), (Cout * Cin, Cin, 1))
+            dxh = torch.empty((B, Hi, Wi, Cin), device=g.device, dtype=in_dtype)
+            _igemm_bf16(dcol, _pack_bf16(wdT, 1, Kp, Cin, 0, Cin, 1), dxh, B=1, Hi=1, Wi=P, Cin=Kp, Ho=1, Wo=P,
+                        Cout=Cin, kh=1, kw=1, stride=1, pad=0, transposed=False)
+            dx = _nchw_view(dxh)
+        if ctx.needs_input_grad[1]:
+            tmp = torch.empty((Cin, Kp), device=g.device, dtype=torch.float32)
+            _wgrad_bf16(xh, dcol, tmp, B=1, Hs=1, Ws=P, Cp=Cin, Hl=1, Wl=P, Cg=Kp, kh=1, kw=1, stride=1, pad=0,
+                        g_is_row=False, dst_sm=Kp, dst_sn=1, dst_stap=0)
+            dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+            _permute3(tmp, dw, (Cin, taps, Cout), (Kp, Cout, 1), (Cout * taps, 1, taps))
+        if has_bias and ctx.needs_input_grad[2]:
+            db = _colsum(g, B * Ho * Wo, Cout)
+        return dx, dw, db, None, None, None
+
+
+class _GDNBF16Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, beta, gamma, inverse, beta_bound, gamma_bound, pedestal):
+        _check(x, beta, gamma)
+        lib = L.load()
+        xh = _as_bf16_nhwc(x)
+        B, H, W, Cc = xh.shape
+        beta_c, gamma_c = beta.contiguous(), gamma.contiguous()
+        beta_e, gamma_e = torch.empty_like(beta_c), torch.empty_like(gamma_c)
+        L.check(lib.lic_gdn_reparam(_ptr(beta_c), _ptr(beta_e), Cc, beta_bound, pedestal, _stream()), "lic_gdn_reparam")
+        L.check(lib.lic_gdn_reparam(_ptr(gamma_c), _ptr(gamma_e), Cc * Cc, gamma_bound, pedestal, _stream()),
+                "lic_gdn_reparam")
+        gT = _pack_bf16(gamma_e, 1, Cc, Cc, 0, 1, Cc)
+        out, norm = torch.empty_like(xh), torch.empty_like(xh)
+        P = B * H * W
+        _igemm_bf16(xh, gT, out, B=1, Hi=1, Wi=P, Cin=Cc, Ho=1, Wo=P, Cout=Cc, kh=1, kw=1, stride=1, pad=0,
+                    transposed=False, bias=beta_e, prologue=1, epilogue=L.EPI_IGDN if inverse else L.EPI_GDN,
+                    out2=norm, aux=xh)
+        ctx.save_for_backward(xh, norm, gamma_e, beta_c, gamma_c)
+        ctx.cfg = (inverse, beta_bound, gamma_bound)
+        return _nchw_view(out)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xh, norm, gamma_e, beta_c, gamma_c = ctx.saved_tensors
+        inverse, beta_bound, gamma_bound = ctx.cfg
+        lib = L.load()
+        g = _as_bf16_nhwc(gy)
+        B, H, W, Cc = xh.shape
+        P = B * H * W
+        t = torch.empty_like(xh)
+        L.check(lib.lic_gdn_dnorm_bf16(_ptr(g), _ptr(xh), _ptr(norm), _ptr(t), xh.numel(), int(inverse), _stream()),
+                "lic_gdn_dnorm_bf16")
+        dx = dbeta = dgamma = None
+        if ctx.needs_input_grad[0]:
+            dxh = torch.empty_like(xh)
+            _igemm_bf16(t, _pack_bf16(gamma_e, 1, Cc, Cc, 0, Cc, 1), dxh, B=1, Hi=1, Wi=P, Cin=Cc, Ho=1, Wo=P, Cout=Cc,
+                        kh=1, kw=1, stride=1, pad=0, transposed=False,
+                        epilogue=L.EPI_IGDN_BWD if inverse else L.EPI_GDN_BWD, aux=g, aux2=xh, aux3=norm)
+            dx = _nchw_view(dxh)
+        if ctx.needs_input_grad[1]:
+            dbe = _colsum_bf16(t, P, Cc)
+            dbeta = torch.empty_like(beta_c)
+            L.check(lib.lic_gdn_reparam_bwd(_ptr(beta_c), _ptr(dbe), _ptr(dbeta), Cc, beta_bound, _stream()),
+                    "lic_gdn_reparam_bwd")
+        if ctx.needs_input_grad[2]:
+            dge = torch.empty_like(gamma_e)
+            _wgrad_bf16(t, xh, dge, B=1, Hs=1, Ws=P, Cp=Cc, Hl=1, Wl=P, Cg=Cc, kh=1, kw=1, stride=1, pad=0,
+                        g_is_row=False, dst_sm=Cc, dst_sn=1, dst_stap=0, sq_g=1)
+            dgamma = torch.empty_like(gamma_c)
+            L.check(lib.lic_gdn_reparam_bwd(_ptr(gamma_c), _ptr(dge), _ptr(dgamma), Cc * Cc, gamma_bound, _stream()),
+                    "lic_gdn_reparam_bwd")
+        return dx, dbeta, dgamma, None, None, None, None
+
+
+def conv2d_bf16(x, weight, bias, stride, padding, out_f32=False):
+    return _ConvBF16Fn.apply(x, weight, bias, stride, padding, 0, False, out_f32)
+
+
+def conv_transpose2d_bf16(x, weight, bias, stride, padding, output_padding, out_f32=False):
+    return _ConvBF16Fn.apply(x, weight, bias, stride, padding, output_padding, True, out_f32)
+
+
+def image_conv2d_bf16(x, weight, bias, stride, padding):
+    return _ImageConvBF16Fn.apply(x, weight, bias, stride, padding)
+
+
+def image_conv_transpose2d_bf16(x, weight, bias, stride, padding, output_padding):
+    return _ImageConvTBF16Fn.apply(x, weight, bias, stride, padding, output_padding)
+
+
+def gdn_bf16(x, beta, gamma, inverse, beta_bound, gamma_bound, pedestal=PEDESTAL):
+    return _GDNBF16Fn.apply(x, beta, gamma, bool(inverse), float(beta_bound), float(gamma_bound), float(pedestal))

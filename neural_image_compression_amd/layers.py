@@ -16,6 +16,7 @@ import torch.nn as nn
 from torch import Tensor
 
 from . import functional as F_
+from . import functional_bf16 as FB_
 
 
 def _pair(v):
@@ -23,10 +24,17 @@ def _pair(v):
 
 
 class Conv2d(nn.Conv2d):
-    def forward(self, x: Tensor, leaky: bool = False, slope: float = 0.01, residual=None) -> Tensor:
+    def forward(self, x: Tensor, leaky: bool = False, slope: float = 0.01, residual=None, bf16: bool = False,
+                out_f32: bool = False) -> Tensor:
         if self.groups != 1 or _pair(self.dilation) != 1:
             raise NotImplementedError("groups/dilation are not used by the reference models")
         s, p = _pair(self.stride), _pair(self.padding)
+        if bf16:  # bf16-storage path (BASELINE config 3): plain conv + bias only
+            if leaky or residual is not None:
+                raise NotImplementedError("bf16 mode covers the 5x5 conv/GDN stacks")
+            if self.in_channels < 4:
+                return FB_.image_conv2d_bf16(x, self.weight, self.bias, s, p)
+            return FB_.conv2d_bf16(x, self.weight, self.bias, s, p, out_f32)
         if self.in_channels < 4:  # RGB stem: im2col + dense MFMA GEMM
             y = F_.image_conv2d(x, self.weight, self.bias, s, p, leaky, slope)
             return y if residual is None else y + residual
@@ -34,10 +42,17 @@ class Conv2d(nn.Conv2d):
 
 
 class ConvTranspose2d(nn.ConvTranspose2d):
-    def forward(self, x: Tensor, leaky: bool = False, slope: float = 0.01, residual=None) -> Tensor:
+    def forward(self, x: Tensor, leaky: bool = False, slope: float = 0.01, residual=None, bf16: bool = False,
+                out_f32: bool = False) -> Tensor:
         if self.groups != 1 or _pair(self.dilation) != 1:
             raise NotImplementedError("groups/dilation are not used by the reference models")
         s, p, op = _pair(self.stride), _pair(self.padding), _pair(self.output_padding)
+        if bf16:
+            if leaky or residual is not None:
+                raise NotImplementedError("bf16 mode covers the 5x5 conv/GDN stacks")
+            if self.out_channels < 4:
+                return FB_.image_conv_transpose2d_bf16(x, self.weight, self.bias, s, p, op)
+            return FB_.conv_transpose2d_bf16(x, self.weight, self.bias, s, p, op, out_f32)
         if self.out_channels < 4:  # RGB head: dense MFMA GEMM + col2im
             if leaky or residual is not None:
                 raise NotImplementedError
@@ -55,6 +70,19 @@ class LeakyReLU(nn.Module):
 
     def forward(self, x: Tensor) -> Tensor:
         return F_.leaky_relu(x, self.negative_slope)
+
+
+def run_bf16(seq: nn.Sequential, x: Tensor) -> Tensor:
+    """bf16-storage execution of a conv/GDN stack: bf16 between layers, fp32 out of the last one."""
+    mods = list(seq)
+    for i, m in enumerate(mods):
+        if isinstance(m, (Conv2d, ConvTranspose2d)):
+            x = m(x, bf16=True, out_f32=(i == len(mods) - 1))
+        elif isinstance(m, GDN):
+            x = m(x, bf16=True)
+        else:
+            raise NotImplementedError(f"bf16 mode does not cover {type(m).__name__}")
+    return x.float() if x.dtype != torch.float32 else x
 
 
 def run_fused(seq: nn.Sequential, x: Tensor) -> Tensor:
@@ -109,7 +137,12 @@ class GDN(nn.Module):
         self.gamma_reparam = NonNegativeParametrizer()
         self.gamma = nn.Parameter(self.gamma_reparam.init(float(gamma_init) * torch.eye(int(in_channels))))
 
-    def forward(self, x: Tensor, residual=None) -> Tensor:
+    def forward(self, x: Tensor, residual=None, bf16: bool = False) -> Tensor:
+        if bf16:
+            if residual is not None:
+                raise NotImplementedError
+            return FB_.gdn_bf16(x, self.beta, self.gamma, self.inverse, self.beta_reparam.bound_value,
+                                self.gamma_reparam.bound_value, self.beta_reparam.pedestal_value)
         return F_.gdn(x, self.beta, self.gamma, self.inverse, self.beta_reparam.bound_value,
                       self.gamma_reparam.bound_value, self.beta_reparam.pedestal_value, residual)
 

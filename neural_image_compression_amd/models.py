@@ -36,6 +36,18 @@ class _HyperpriorContextModel(nn.Module):
         self.entropy_parameters = EntropyParameters(latent_channels=self.M, hyper_latent_channels=self.H,
                                                     K=self.K)
 
+    def set_precision(self, precision: str = "fp32"):
+        """"fp32" (default, the reference's arithmetic) or "bf16": bf16 activation storage and bf16 MFMA
+        with fp32 accumulation inside the analysis / synthesis stacks (BASELINE config 3; not in the
+        reference).  Latents, hyper path, likelihoods and the loss stay fp32."""
+        if precision not in ("fp32", "bf16"):
+            raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
+        if precision == "bf16" and not isinstance(self.encoder, Encoder5x5):
+            raise NotImplementedError("bf16 mode covers the 5x5 conv/GDN stacks (JointAutoregressiveHierarchical)")
+        self.encoder.precision = precision
+        self.decoder.precision = precision
+        return self
+
     def forward(self, x: torch.Tensor, training: bool = True, noise=None):
         """`noise` (test hook, not in the reference): (u_z, u_y) uniform [0,1) tensors used instead
         of torch.rand_like, in the reference's draw order (z first, Models.py:57-58)."""

@@ -1,0 +1,201 @@
+"""bf16-storage mode (BASELINE config 3; not in the reference) on the GPU.
+
+Declared tolerances (the 1e-4 bar of the north star applies to the fp32 path only):
+  * kernels fed bf16-exact operands must match the fp32 oracle on the SAME rounded operands to
+    fp32-accumulation accuracy (1e-4 of the tensor scale) when they write fp32, and to one bf16
+    rounding (2^-8 relative, plus the tensor-scale floor) when they write bf16;
+  * the whole model in bf16 mode vs the same model in fp32 mode: bpp / PSNR / loss within 3 %,
+    every large parameter gradient with cosine similarity >= 0.98.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+import golden_recipe as R
+
+pytestmark = pytest.mark.gpu
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def env():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import neural_image_compression_amd as nic
+    from neural_image_compression_amd import functional_bf16 as FB
+    from oracle import oracle as O
+    return nic, FB, O, torch.device("cuda:0")
+
+
+def rb(a):
+    """round a numpy fp32 array to bf16-representable values"""
+    return torch.from_numpy(np.ascontiguousarray(a)).to(BF).float().numpy()
+
+
+def dev(a, d, dtype=None, grad=False):
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(d)
+    if t.dim() == 4:
+        t = t.contiguous(memory_format=torch.channels_last)
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.requires_grad_(grad)
+
+
+def host(t):
+    return t.detach().float().cpu().contiguous().numpy()
+
+
+def scale_close(a, b, rel, what):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    s = max(np.abs(b).max(), 1e-30)
+    assert np.abs(a - b).max() <= rel * s, f"{what}: {np.abs(a - b).max():.3e} vs scale {s:.3e}"
+
+
+def bf16_close(a, b, what):
+    """one bf16 rounding of b: |a-b| <= 2^-8 |b| + 2^-8 * 1e-2 * scale"""
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    s = max(np.abs(b).max(), 1e-30)
+    err = np.abs(a - b)
+    assert (err <= 2.0 ** -8 * np.abs(b) + 2.0 ** -8 * 1e-2 * s + 1e-30).all(), f"{what}: {err.max():.3e} (scale {s:.3e})"
+
+
+@pytest.mark.parametrize("k,s,p,ci,co,H,W,B,tr,op", [(5, 2, 2, 64, 64, 16, 16, 2, False, 0),
+                                                     (5, 2, 2, 32, 192, 10, 18, 2, False, 0),
+                                                     (3, 1, 1, 16, 24, 8, 8, 2, False, 0),
+                                                     (5, 2, 2, 64, 64, 6, 6, 2, True, 1),
+                                                     (5, 2, 2, 192, 32, 5, 3, 1, True, 1),
+                                                     (1, 1, 0, 192, 80, 4, 6, 2, False, 0)])
+def test_conv_bf16_ops(env, k, s, p, ci, co, H, W, B, tr, op):
+    nic, FB, O, d = env
+    r = np.random.RandomState(ci + co)
+    x = rb(r.randn(B, ci, H, W).astype(np.float32))
+    wshape = (ci, co, k, k) if tr else (co, ci, k, k)
+    w = rb((r.randn(*wshape) / math.sqrt(ci * k * k)).astype(np.float32))
+    b = r.randn(co).astype(np.float32)
+    tw, tb = dev(w, d).contiguous().requires_grad_(True), dev(b, d, grad=True)
+    fwd = (lambda t, f32: FB.conv_transpose2d_bf16(t, tw, tb, s, p, op, f32)) if tr else \
+        (lambda t, f32: FB.conv2d_bf16(t, tw, tb, s, p, f32))
+    y_ref = O.convT2d_fwd(x, w, b, s, p, op) if tr else O.conv2d_fwd(x, w, b, s, p)
+    # fp32 output: only the accumulation order differs from the oracle
+    tx = dev(x, d, BF, grad=True)
+    y32 = fwd(tx, True)
+    assert y32.dtype == torch.float32
+    scale_close(host(y32), y_ref, 1e-4, "y (fp32 out)")
+    dy = rb(r.randn(*y_ref.shape).astype(np.float32))
+    y32.backward(dev(dy, d))
+    dx, dw, db = (O.convT2d_bwd(x, w, dy, s, p, op) if tr else O.conv2d_bwd(x, w, dy, s, p))
+    bf16_close(host(tx.grad), dx, "dx (bf16 out)")
+    scale_close(host(tw.grad), dw, 1e-4, "dw")
+    scale_close(host(tb.grad), db, 1e-4, "db")
+    # bf16 output: one extra rounding
+    ybf = fwd(dev(x, d, BF), False)
+    assert ybf.dtype == BF
+    bf16_close(host(ybf), y_ref, "y (bf16 out)")
+
+
+def test_image_layers_bf16(env):
+    nic, FB, O, d = env
+    r = np.random.RandomState(3)
+    x = r.rand(2, 3, 32, 32).astype(np.float32)
+    w = rb((r.randn(64, 3, 5, 5) / math.sqrt(75)).astype(np.float32))
+    b = r.randn(64).astype(np.float32)
+    tw, tb = dev(w, d).contiguous().requires_grad_(True), dev(b, d, grad=True)
+    y = FB.image_conv2d_bf16(dev(x, d), tw, tb, 2, 2)
+    y_ref = O.conv2d_fwd(rb(x), w, b, 2, 2)
+    bf16_close(host(y), y_ref, "stem y")
+    dy = rb(r.randn(*y_ref.shape).astype(np.float32))
+    y.backward(dev(dy, d, BF))
+    _, dw, db = O.conv2d_bwd(rb(x), w, dy, 2, 2, need_dx=False)
+    scale_close(host(tw.grad), dw, 1e-4, "stem dw")
+    scale_close(host(tb.grad), db, 1e-4, "stem db")
+    # head
+    xh = rb(r.randn(2, 64, 8, 8).astype(np.float32))
+    wt = rb((r.randn(64, 3, 5, 5) / math.sqrt(64 * 25)).astype(np.float32))
+    bt = r.randn(3).astype(np.float32)
+    twt, tbt = dev(wt, d).contiguous().requires_grad_(True), dev(bt, d, grad=True)
+    txh = dev(xh, d, BF, grad=True)
+    out = FB.image_conv_transpose2d_bf16(txh, twt, tbt, 2, 2, 1)
+    assert out.dtype == torch.float32
+    out_ref = O.convT2d_fwd(xh, wt, bt, 2, 2, 1)
+    # the per-tap columns are bf16: up to 9 rounded terms per output
+    scale_close(host(out), out_ref, 2e-2, "head out")
+    g = r.randn(*out_ref.shape).astype(np.float32)
+    out.backward(dev(g, d))
+    dx, dw, db = O.convT2d_bwd(xh, wt, rb(g), 2, 2, 1)
+    scale_close(host(txh.grad), dx, 2e-2, "head dx")
+    scale_close(host(twt.grad), dw, 1e-4, "head dw")
+    dbf = O.convT2d_bwd(xh, wt, g, 2, 2, 1)[2]
+    scale_close(host(tbt.grad), dbf, 1e-4, "head db")
+
+
+@pytest.mark.parametrize("inverse", [False, True])
+def test_gdn_bf16(env, inverse):
+    nic, FB, O, d = env
+    from neural_image_compression_amd.layers import GDN
+    C = 64
+    r = np.random.RandomState(5)
+    x = rb(r.randn(2, C, 6, 5).astype(np.float32))
+    m = GDN(C, inverse=inverse).to(d)
+    beta_p, gamma_p = R.make_param("g.beta", (C,), 3), R.make_param("g.gamma", (C, C), 3)
+    with torch.no_grad():
+        m.beta.copy_(torch.from_numpy(beta_p))
+        m.gamma.copy_(torch.from_numpy(gamma_p))
+    tx = dev(x, d, BF, grad=True)
+    y = m(tx, bf16=True)
+    beta_e, gamma_e = O.gdn_reparam(beta_p, 1e-6), O.gdn_reparam(gamma_p, 0.0)
+    y_ref, nrm = O.gdn_fwd(x, beta_e, gamma_e, inverse)
+    scale_close(host(y), y_ref, 2e-2, "gdn y")  # x^2 and gamma are rounded to bf16 before the contraction
+    dy = rb(r.randn(*x.shape).astype(np.float32))
+    y.backward(dev(dy, d, BF))
+    dx, dbe, dge = O.gdn_bwd(x, nrm, gamma_e, dy, inverse)
+    scale_close(host(tx.grad), dx, 3e-2, "gdn dx")
+    scale_close(host(m.beta.grad), O.gdn_reparam_bwd(beta_p, dbe, 1e-6), 3e-2, "dbeta")
+    scale_close(host(m.gamma.grad), O.gdn_reparam_bwd(gamma_p, dge, 0.0), 3e-2, "dgamma")
+
+
+@pytest.mark.parametrize("M,K,B", [(64, 3, 2), (128, 3, 2)])
+def test_model_bf16_vs_fp32(env, M, K, B):
+    """Config 3's model (JAH, K=3) in bf16 mode against the same weights in fp32 mode."""
+    nic, FB, O, d = env
+    model = nic.JointAutoregressiveHierarchical(M, K)
+    ks = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
+    st = R.make_state(ks, 21)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
+    model = model.to(d)
+    x = dev(R.make_image(B, 128, 128, 22), d)
+    uz = dev(R.make_noise((B, M, 2, 2), 23), d)
+    uy = dev(R.make_noise((B, M, 8, 8), 24), d)
+    res, grads = {}, {}
+    for prec in ("fp32", "bf16"):
+        model.set_precision(prec)
+        model.zero_grad(set_to_none=True)
+        out = model(x, noise=(uz, uy))
+        assert out["x_hat"].dtype == torch.float32 and out["y"].dtype == torch.float32
+        r_ = nic.rd_loss(out, x, 0.01)
+        r_["loss"].backward()
+        res[prec] = r_
+        grads[prec] = {k: p.grad.detach().double().flatten() for k, p in model.named_parameters()}
+    for k in ("bpp_y", "bpp_z", "bpp_total", "mse"):
+        a, b = res["bf16"][k], res["fp32"][k]
+        assert abs(a - b) <= 0.03 * abs(b), (k, a, b)
+    assert abs(res["bf16"]["psnr"] - res["fp32"]["psnr"]) <= 0.15, (res["bf16"]["psnr"], res["fp32"]["psnr"])
+    worst = ("", 1.0)
+    for k, g in grads["fp32"].items():
+        if g.numel() < 1024:
+            continue
+        cs = float(torch.dot(g, grads["bf16"][k]) / (g.norm() * grads["bf16"][k].norm() + 1e-300))
+        if cs < worst[1]:
+            worst = (k, cs)
+    assert worst[1] >= 0.98, worst
+    model.set_precision("fp32")
+
+
+def test_set_precision_validation(env):
+    nic, FB, O, d = env
+    with pytest.raises(ValueError):
+        nic.JointAutoregressiveHierarchical(8, 1).set_precision("fp16")
+    with pytest.raises(NotImplementedError):
+        nic.HierarchicalMixtureResidual(8, 1).set_precision("bf16")
