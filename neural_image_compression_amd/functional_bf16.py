@@ -62,7 +62,20 @@ def _igemm_bf16(inp, w_packed, out, *, B, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, str
     d.kh, d.kw, d.stride, d.pad = kh, kw, stride, pad
     d.transposed, d.prologue, d.epilogue = int(transposed), prologue, epilogue
     d.tap_mask, d.slope = 0, 0.01
+    from . import functional as F_
+    if F_.PROFILE is None:
+        L.check(L.load().lic_igemm_bf16(C.byref(d), int(out.dtype == torch.float32), _stream()), "lic_igemm_bf16")
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     L.check(L.load().lic_igemm_bf16(C.byref(d), int(out.dtype == torch.float32), _stream()), "lic_igemm_bf16")
+    e1.record()
+    if transposed and stride == 2:  # live taps per output pixel: kh*kw/4 on average
+        macs = B * Ho * Wo * (kh * kw) * Cin * Cout // 4
+    else:
+        macs = B * Ho * Wo * kh * kw * Cin * Cout
+    F_.PROFILE.append(("igemm_bf16_kernel", 2 * macs, 2 * B * Hi * Wi * Cin + out.element_size() * B * Ho * Wo * Cout,
+                       e0, e1))
 
 
 def _wgrad_bf16(p, g, dst, *, B, Hs, Ws, Cp, Hl, Wl, Cg, kh, kw, stride, pad, g_is_row, dst_sm, dst_sn, dst_stap,
@@ -77,7 +90,16 @@ def _wgrad_bf16(p, g, dst, *, B, Hs, Ws, Cp, Hl, Wl, Cg, kh, kw, stride, pad, g_
     lib = L.load()
     nbytes = lib.lic_wgrad_bf16_workspace_bytes(C.byref(d))
     ws = torch.empty((max(nbytes, 4) + 3) // 4, device=p.device, dtype=torch.float32)
+    from . import functional as F_
+    if F_.PROFILE is None:
+        L.check(lib.lic_wgrad_bf16(C.byref(d), _ptr(ws), nbytes, _stream()), "lic_wgrad_bf16")
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
     L.check(lib.lic_wgrad_bf16(C.byref(d), _ptr(ws), nbytes, _stream()), "lic_wgrad_bf16")
+    e1.record()
+    F_.PROFILE.append(("wgrad_bf16_kernel+reduce", 2 * B * Hs * Ws * kh * kw * Cp * Cg,
+                       2 * (B * Hs * Ws * Cp + B * Hl * Wl * Cg), e0, e1))
 
 
 def _colsum_bf16(t2d, P, Cc):
