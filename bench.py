@@ -2,7 +2,7 @@
 """Headline benchmark: images/s of one training step (forward + rd_loss + backward + Adam step)
 of the hot path on synthetic 256x256 RGB batches, batch 32 per GPU.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3k|4|5] [--no-cpu-baseline]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|3k|2h|4|5] [--no-cpu-baseline]
 
 N > 1 is launched by the driver as  python -m torch.distributed.run --nproc-per-node N ... bench.py
 --gpus N ...: one rank per GPU, images sharded (32 per rank, weak scaling), one RCCL all-reduce of
@@ -11,6 +11,14 @@ the gradients per step.  Rank 0 prints ONE JSON line.
 Workload (config 2, BASELINE.json configs[1]): JointAutoregressiveHierarchical(192, K=1)
 (the nearest reference surface to "scale hyperprior capacity 192"), B=32,
 256x256, fp32, lambda=0.01, default-initialised weights (seed 0), x = rand (seed 1234+rank).
+Other configs are parity-test cases that can be timed the same way: 3 = BASELINE configs[2]
+(JAH(128, K=3), bf16 storage in the conv/GDN stacks), 3k / 2h = the same models in the other
+precision, 4 = configs[3]'s per-GPU work, 5 = configs[4] (16x512x512).
+
+Extra fields of the JSON line: `roofline` (dominant kernel by time, HIP events around every MFMA
+launch of the timed region), `kernels` (per-kernel ms and TFLOP/s), `analysis_hyperprior_fwd`
+(the scope the north star quotes its target on, timed separately after the K steps) and
+`cpu_baseline` (oracle/torch_ref.py on the host cores, bounded sample).
 """
 from __future__ import annotations
 
@@ -43,8 +51,10 @@ BF16_MFMA_PEAK_TF = 2500.0
 
 
 def cpu_baseline(M, K, H, W, lam, budget_s=25.0):
-    """The CPU oracle (oracle/lic_oracle.c, 'port') timed on this host's cores on a bounded sample
-    of the same workload: one fwd + rd_loss + bwd of ONE image batch slice."""
+    """The CPU restatement ('port') timed on this host's cores on a bounded sample of the same
+    workload: fwd + rd_loss + bwd of up to 16 images in batches of 4 through oracle/torch_ref.py
+    (torch CPU ops on <=16 threads: the library the reference's own CPU path runs on) -> `value`;
+    one image through the plain-C oracle (oracle/lic_oracle.c) -> `c_oracle_images_per_s`."""
     import numpy as np
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import golden_recipe as R
@@ -82,6 +92,36 @@ def cpu_baseline(M, K, H, W, lam, budget_s=25.0):
             "sample": f"{n} images {H}x{W} in batches of {B}, fwd+rd_loss+bwd, JAH M={M} K={K}, fp32, "
                       f"oracle/torch_ref.py (torch CPU ops, {cores} threads)",
             "c_oracle_images_per_s": round(c_ips, 4)}
+
+
+def analysis_hyperprior_fwd(model, x, F_, bf16, reps=5):
+    """Forward of everything but the synthesis transform (the north star's target scope), timed
+    apart from the K steps: wall time of `reps` passes, algorithmic FLOP / bytes from the launch
+    plans of its MFMA kernels, and the roofline time max(t_flop, t_hbm) summed per launch."""
+    with torch.no_grad():
+        for _ in range(2):
+            model.analysis_hyperprior(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            model.analysis_hyperprior(x)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        F_.PROFILE = []
+        model.analysis_hyperprior(x)
+        torch.cuda.synchronize()
+        prof, F_.PROFILE = F_.PROFILE, None
+    flops = sum(p[1] for p in prof)
+    abytes = sum(p[2] for p in prof)
+    t_roof = sum(max(p[1] / ((BF16_MFMA_PEAK_TF if "bf16" in p[0] else FP32_MFMA_PEAK_TF) * 1e12),
+                     p[2] / (HBM_PEAK_GBS * 1e9)) for p in prof) * 1e3
+    mfma_ms = sum(p[3].elapsed_time(p[4]) for p in prof)
+    return {"ms": round(ms, 3), "mfma_kernel_ms": round(mfma_ms, 3), "alg_gflop": round(flops / 1e9, 1),
+            "alg_gb": round(abytes / 1e9, 3), "tflops": round(flops / ms / 1e9, 2),
+            "hbm_frac": round(abytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+            "mfma_frac": round(flops / (ms * 1e-3) / 1e12 / (BF16_MFMA_PEAK_TF if bf16 else FP32_MFMA_PEAK_TF), 4),
+            "t_roof_ms": round(t_roof, 3), "roofline_fraction": round(t_roof / ms, 4),
+            "images_per_s": round(x.shape[0] / ms * 1e3, 1)}
 
 
 def main():
@@ -211,6 +251,8 @@ def main():
                                    "tflops": round(v[2] / max(v[1], 1e-12) / 1e12, 2)} for k, v in agg.items()}
             mfma_s = sum(v[1] for v in agg.values())
             line["mfma_kernel_share_of_step"] = round(mfma_s / el, 4)
+        if world == 1:
+            line["analysis_hyperprior_fwd"] = analysis_hyperprior_fwd(model, x, F_, bf16)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(M, K, H, W, lam)

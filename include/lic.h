@@ -58,8 +58,9 @@ enum lic_epilogue {
  *   transposed == 0:  out[b,oh,ow,:] = sum_{r,s} in[b, oh*stride-pad+r, ow*stride-pad+s, :] . W[r,s]
  *   transposed == 1:  out[b,oy,ox,:] = sum_{r,s : (oy+pad-r) % stride == 0 ...}
  *                                       in[b,(oy+pad-r)/stride,(ox+pad-s)/stride,:] . W[r,s]
- *   W is the packed weight produced by lic_pack_weight: [kh*kw][ceil(Cin/16)][ceil32(Cout)][16]
- *   (the MFMA B-operand order; lanes read it straight from L2 into registers).
+ *   W is the packed weight produced by lic_pack_weight: [kh*kw][ceil(Cin/16)][ceil32(Cout)/32][2][64][4]
+ *   (an opaque MFMA-operand order: element (k, n) of a chunk sits at lane (n%32) + 32*((k%16)/8),
+ *   load q = (k%8)/4, float k%4)
  * Replaces: nn.Conv2d / nn.ConvTranspose2d forward and their input gradients
  *   (Components.py:10-16,39-45,69-73,99-103; Layers.py:21,38,40,43,74,76,99,101,103;
  *   ParametersModels.py:22-34; ContextModels.py:19-20 via tap_mask), the GDN/IGDN channel

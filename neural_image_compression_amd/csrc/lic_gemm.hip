@@ -5,6 +5,7 @@
 // through LDS, the next chunk's global loads are issued before the current chunk's MFMAs, and
 // 3-4 workgroups per CU cover each other's load/store phases.
 #include "lic_common.h"
+#include <stdlib.h>
 
 thread_local int g_lic_last_hip_error = 0;
 
@@ -32,9 +33,10 @@ __device__ __forceinline__ int fdiv(int n, FastDiv f) {
 //  * A (activations): each 16-deep K chunk is gathered global -> registers -> LDS ([BM][16+4]
 //    floats, conflict-free ds_read_b128 fragments), double-buffered so one barrier per chunk
 //    suffices; the loads of chunk c+2 are issued before the MFMAs of chunk c.
-//  * B (weights): never touches LDS.  lic_pack_weight lays them out [tap][chunk][Npad][16] so
-//    that lane (col j, half h) of a wave reads its 8 K-values of a chunk as two 16-byte loads
-//    straight into the MFMA B-operand registers (L2-resident, zero-padded: no guards).
+//  * B (weights): never touches LDS.  lic_pack_weight lays them out
+//    [tap][chunk][Npad/32][2][64 lanes][4] so that lane (col j, half h) of a wave reads its 8
+//    K-values of a chunk as two 16-byte loads, each a contiguous 1 KiB per wave, straight into
+//    the MFMA B-operand registers (L2-resident, zero-padded: no guards).
 // Per chunk a wave issues TM*TN*8 MFMAs (up to 48 = 3072 cycles) against ~10 memory
 // instructions, which keeps LDS (the limiter of the first version of this kernel) nearly idle.
 // ------------------------------------------------------------------------------------------------
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   f32x4 ra[APASS];
   bool ra_ok[APASS];
   // this lane's B-operand address inside a (tap, chunk) panel: column n, K-half lh
-  const float* wlane = p.w + ((long)(n0 + wn0 + li) * IG_BK + lh * 8);
+  const float* wlane = p.w + ((long)((n0 + wn0) >> 5) * 512 + lane * 4);
 
   // Issue the global loads of one A chunk.  On the vector path nothing here consumes a loaded
   // value (out-of-range lanes load from a safe address and are zeroed when the registers are
@@ -212,8 +214,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   // dead 32-column tiles (beyond Npad) re-read the wave's last live tile instead of branching
   int b_off[TN];
 #pragma unroll
-  for (int b = 0; b < TN; ++b) b_off[b] = (b < n_live ? b : (n_live > 0 ? n_live - 1 : 0)) * 32 * IG_BK;
-  if (n_live == 0) wlane = p.w + lh * 8;
+  for (int b = 0; b < TN; ++b) b_off[b] = (b < n_live ? b : (n_live > 0 ? n_live - 1 : 0)) * 512;
+  if (n_live == 0) wlane = p.w + lane * 4;
   auto load_b = [&](f32x4 (&rb)[TN][2], int tapi, int cb) {
     const bool past = tapi > last_tap;
     const int tap = p.taps[phase][past ? last_tap : tapi];
@@ -221,7 +223,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
       rb[b][0] = *reinterpret_cast<const f32x4*>(src + b_off[b]);
-      rb[b][1] = *reinterpret_cast<const f32x4*>(src + b_off[b] + 4);
+      rb[b][1] = *reinterpret_cast<const f32x4*>(src + b_off[b] + 256);
     }
   };
   auto compute = [&](int buf, const f32x4 (&rb)[TN][2]) {
@@ -453,19 +455,24 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 
 static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
-// ---- weight packing: dst[tap][chunk][n][16], zero padded to Npad = ceil32(N), K to 16 ---------
+// ---- weight packing: dst[tap][chunk][n/32][q][lane][4], zero padded to Npad = ceil32(N), K to 16.
+// Lane (col li = lane&31, K-half lh = lane>>5) of a wave owns k = lh*8 + q*4 + e of column
+// n = 32*tile + li, so each of its two B loads per 32-column tile reads lane*16 B of one
+// contiguous 1 KiB block (fully coalesced, whole cache lines).
 __global__ __launch_bounds__(256) void pack_weight_kernel(const float* src, float* dst, int taps, int K,
                                                           int N, int cpt, int Npad, long s_tap, long s_k,
                                                           long s_n) {
   const long total = (long)taps * cpt * Npad * IG_BK;
+  const int ntile = Npad >> 5;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int kk = (int)(i & (IG_BK - 1));
-    long t = i >> 4;
-    const int n = (int)(t % Npad);
-    t /= Npad;
+    const int e = (int)(i & 3), lane = (int)((i >> 2) & 63), q = (int)((i >> 8) & 1);
+    long t = i >> 9;
+    const int tile = (int)(t % ntile);
+    t /= ntile;
     const int cb = (int)(t % cpt);
     const int tap = (int)(t / cpt);
-    const int k = cb * IG_BK + kk;
+    const int n = tile * 32 + (lane & 31);
+    const int k = cb * IG_BK + (lane >> 5) * 8 + q * 4 + e;
     dst[i] = (k < K && n < N) ? src[tap * s_tap + k * s_k + n * s_n] : 0.0f;
   }
 }
@@ -772,8 +779,19 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
   const int li = lane & 31, lh = lane >> 5;
-  const int mt = blockIdx.x / p.NTt, nt = blockIdx.x % p.NTt;
-  const int tap = blockIdx.y, split = blockIdx.z;
+  // XCD-aware bijective remap: the hardware deals workgroup ids round-robin over the 8 XCDs; give
+  // each XCD a contiguous range of K splits, so the (tile, tap) workgroups that stream the same
+  // pixel range share one L2 instead of pulling it through the fabric into all eight.
+  int wg = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, rr = nwg & 7, xcd = wg & 7, idx = wg >> 3;
+    wg = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+  }
+  const int tiles = p.MTt * p.NTt;
+  const int tile = wg % tiles;
+  wg /= tiles;
+  const int tap = wg % p.ntaps, split = wg / p.ntaps;
+  const int mt = tile / p.NTt, nt = tile - mt * p.NTt;
   const int m0 = mt * BMt, n0 = nt * BNt;
   const int r = tap / p.kw, s = tap - r * p.kw;
   const int c_begin = split * p.chunks_per_split;
@@ -922,6 +940,128 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     }
 }
 
+// 16 zero bytes: the source of LDS-DMA lanes that fall on padding / past the last pixel
+__device__ __attribute__((aligned(16))) float g_lic_zero16[4];
+
+// LDS-DMA variant of wgrad_kernel for full tiles without a squaring prologue: both operands go
+// global -> LDS with `global_load_lds_dwordx4` (no staging registers, no ds_write pass, no vmcnt
+// wait in front of an LDS store).  The LDS image is [64-channel sub-tile][16 px][64 ch]: thread t
+// owns pixel t/16, channels (t%16)*4.. of every sub-tile, i.e. byte t*16 of it -- exactly the
+// wave-linear destination the DMA writes.  Two buffers; each iteration is
+//   __syncthreads (vmcnt(0): my DMA of chunk c landed; barrier: everyone's did, and everyone is
+//   done reading chunk c-1)  ->  issue DMA of chunk c+1  ->  MFMAs of chunk c.
+template <int TM, int TN>
+__global__ __launch_bounds__(256) void wgrad_glds_kernel(const WgradParams p) {
+  constexpr int BMt = 64 * TM, BNt = 64 * TN, NS = TM + TN;
+  constexpr int WM = BMt / 2, WN = BNt / 2;
+  __shared__ __attribute__((aligned(16))) float smem[2][NS][WG_BK * 64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  const int li = lane & 31, lh = lane >> 5;
+  int wg = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, rr = nwg & 7, xcd = wg & 7, idx = wg >> 3;
+    wg = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+  }
+  const int tiles = p.MTt * p.NTt;
+  const int tile = wg % tiles;
+  wg /= tiles;
+  const int tap = wg % p.ntaps, split = wg / p.ntaps;
+  const int mt = tile / p.NTt, nt = tile - mt * p.NTt;
+  const int m0 = mt * BMt, n0 = nt * BNt;
+  const int r = tap / p.kw, s = tap - r * p.kw;
+  const int c_begin = split * p.chunks_per_split;
+  const int c_end = min(p.nchunks, c_begin + p.chunks_per_split);
+  const int nloc = c_end - c_begin;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.0f;
+
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const int kr = tid >> 4, c16 = (tid & 15) * 4;
+  // chunk indices past the end are clamped to the last one (harmless duplicate DMA into the idle buffer)
+  auto issue = [&](int c, int buf) {
+    const long pk = (long)(c < c_end ? c : c_end - 1) * WG_BK + kr;
+    const bool inb = pk < p.Ps;
+    const long pix = inb ? pk : 0;
+    const int b = fdiv((int)pix, p.dHW);
+    const int rem = (int)pix - b * p.Hs * p.Ws;
+    const int hs = fdiv(rem, p.dW), ws = rem - hs * p.Ws;
+    const int hl = hs * p.stride - p.pad + r, wl = ws * p.stride - p.pad + s;
+    const bool gok = inb && hl >= 0 && wl >= 0 && hl < p.Hl && wl < p.Wl;
+    const long gpix = ((long)b * p.Hl + hl) * p.Wl + wl;
+    const float* rowp = (p.row.gathered ? gok : inb)
+                            ? p.row.ptr + (p.row.gathered ? gpix : pix) * p.row.ld + m0 + c16
+                            : nullptr;
+    const float* colp = (p.col.gathered ? gok : inb)
+                            ? p.col.ptr + (p.col.gathered ? gpix : pix) * p.col.ld + n0 + c16
+                            : nullptr;
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(rowp ? rowp + 64 * j : g_lic_zero16),
+                                       (lptr_t)&smem[buf][j][wave * 256], 16, 0, 0);
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      __builtin_amdgcn_global_load_lds((gptr_t)(colp ? colp + 64 * j : g_lic_zero16),
+                                       (lptr_t)&smem[buf][TM + j][wave * 256], 16, 0, 0);
+  };
+  auto compute = [&](int buf) {
+    float af[TM][8], bf[TN][8];
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      const int ch = wm0 + a * 32;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) af[a][t] = smem[buf][ch >> 6][(lh * 8 + t) * 64 + (ch & 63) + li];
+    }
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      const int ch = wn0 + b * 32;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) bf[b][t] = smem[buf][TM + (ch >> 6)][(lh * 8 + t) * 64 + (ch & 63) + li];
+    }
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][t], bf[b][t], acc[a][b], 0, 0, 0);
+  };
+
+  if (nloc > 0) {
+    issue(c_begin, 0);
+    int c = 0;
+    for (; c + 1 < nloc; c += 2) {  // branch-free body, single exit (see igemm_kernel)
+      __syncthreads();
+      issue(c_begin + c + 1, 1);
+      compute(0);
+      __builtin_amdgcn_sched_barrier(0);  // keep the vmcnt(0)+barrier BEHIND this chunk's MFMAs
+      __syncthreads();
+      issue(c_begin + c + 2, 0);
+      compute(1);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    __syncthreads();  // drains the last (possibly duplicate) DMA before the buffers die
+    if (c < nloc) compute(0);
+  }
+  float* slab = p.slabs + ((long)split * p.ntaps + tap) * p.row.C * p.col.C;
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int m = m0 + wm0 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
+#pragma unroll
+      for (int b = 0; b < TN; ++b) slab[(long)m * p.col.C + n0 + wn0 + b * 32 + li] = acc[a][b][q];
+    }
+}
+
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, float* dst, int splitk,
                                                            int ntaps, int Cm, int Cn, long sm, long sn,
                                                            long stap, float scale) {
@@ -965,6 +1105,8 @@ static int wg_plan(const lic_wgrad_desc* d, WgPlan* pl) {
   if (sk > max_sk) sk = max_sk;
   if (sk < 1) sk = 1;
   if (sk > 256) sk = 256;
+  if (sk > 8) sk = (sk + 7) & ~7L;  // whole splits per XCD (see the kernel's remap)
+  if (sk > max_sk) sk = max_sk;
   pl->cps = (int)((pl->nchunks + sk - 1) / sk);
   pl->splitk = (pl->nchunks + pl->cps - 1) / pl->cps;
   return LIC_OK;
@@ -1019,11 +1161,14 @@ LIC_EXPORT int lic_wgrad(const lic_wgrad_desc* d, void* workspace, size_t worksp
   p.dHW = make_fastdiv((unsigned)(d->Hs * d->Ws));
   p.dW = make_fastdiv((unsigned)d->Ws);
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid(pl.MTt * pl.NTt, pl.ntaps, pl.splitk), block(256);
+  dim3 grid(pl.MTt * pl.NTt * pl.ntaps * pl.splitk), block(256);
   const bool full = (pl.Cm % (64 * pl.TM) == 0) && (pl.Cn % (64 * pl.TN) == 0);
+  const bool glds = full && !d->sq_p && !d->sq_g && getenv("LIC_WGRAD_NO_GLDS") == nullptr;
 #define LIC_WGRAD_LAUNCH(tm, tn)                                                      \
   do {                                                                                \
-    if (full)                                                                         \
+    if (glds)                                                                         \
+      hipLaunchKernelGGL((wgrad_glds_kernel<tm, tn>), grid, block, 0, s, p);          \
+    else if (full)                                                                    \
       hipLaunchKernelGGL((wgrad_kernel<tm, tn, true, true>), grid, block, 0, s, p);   \
     else                                                                              \
       hipLaunchKernelGGL((wgrad_kernel<tm, tn, true, false>), grid, block, 0, s, p);  \

@@ -532,8 +532,17 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradHParams p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
   const int li = lane & 31, lh = lane >> 5;
-  const int mt = blockIdx.x / p.NTt, nt = blockIdx.x % p.NTt;
-  const int tap = blockIdx.y, split = blockIdx.z;
+  // XCD-aware bijective remap: whole K splits per XCD (see wgrad_kernel in lic_gemm.hip)
+  int wg = blockIdx.x;
+  {
+    const int nwg = gridDim.x, q = nwg >> 3, rr = nwg & 7, xcd = wg & 7, idx = wg >> 3;
+    wg = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + idx;
+  }
+  const int tiles = p.MTt * p.NTt;
+  const int tile = wg % tiles;
+  wg /= tiles;
+  const int tap = wg % p.ntaps, split = wg / p.ntaps;
+  const int mt = tile / p.NTt, nt = tile - mt * p.NTt;
   const int m0 = mt * BMt, n0 = nt * BNt;
   const int r = tap / p.kw, s = tap - r * p.kw;
   const int c_begin = split * p.chunks_per_split;
@@ -701,6 +710,8 @@ static int wgh_plan(const lic_wgrad_desc* d, WgHPlan* pl) {
   if (sk > max_sk) sk = max_sk;
   if (sk < 1) sk = 1;
   if (sk > 256) sk = 256;
+  if (sk > 8) sk = (sk + 7) & ~7L;
+  if (sk > max_sk) sk = max_sk;
   pl->cps = (int)((pl->nchunks + sk - 1) / sk);
   pl->splitk = (pl->nchunks + pl->cps - 1) / pl->cps;
   return LIC_OK;
@@ -753,7 +764,7 @@ LIC_EXPORT int lic_wgrad_bf16(const lic_wgrad_desc* d, void* workspace, size_t w
   p.dHW = make_fastdivb((unsigned)(d->Hs * d->Ws));
   p.dW = make_fastdivb((unsigned)d->Ws);
   hipStream_t s = (hipStream_t)stream;
-  dim3 grid(pl.MTt * pl.NTt, pl.ntaps, pl.splitk), block(256);
+  dim3 grid(pl.MTt * pl.NTt * pl.ntaps * pl.splitk), block(256);
   if (pl.TM == 2 && pl.TN == 3)
     hipLaunchKernelGGL((wgrad_bf16_kernel<2, 3>), grid, block, 0, s, p);
   else if (pl.TM == 2 && pl.TN == 2)

@@ -48,9 +48,9 @@ class _HyperpriorContextModel(nn.Module):
         self.decoder.precision = precision
         return self
 
-    def forward(self, x: torch.Tensor, training: bool = True, noise=None):
-        """`noise` (test hook, not in the reference): (u_z, u_y) uniform [0,1) tensors used instead
-        of torch.rand_like, in the reference's draw order (z first, Models.py:57-58)."""
+    def analysis_hyperprior(self, x: torch.Tensor, training: bool = True, noise=None):
+        """Everything of `forward` except the synthesis transform (Models.py:49-97): the scope the
+        north star quotes its roofline target on.  Returns the out-dict without 'x_hat'."""
         if x.shape[2] % 64 or x.shape[3] % 64:
             raise RuntimeError("H and W must be multiples of 64 (phi/psi shapes must agree, Models.py:73)")
         y = self.encoder(x)
@@ -78,11 +78,17 @@ class _HyperpriorContextModel(nn.Module):
             params = {"weights": weights, "mus": mus, "sigmas": sigmas}
         p_z, logp_z = self.factorized_entropy_model.likelihood_and_log(z_in)
         p_y, logp_y = self.conditional.packed_likelihood_and_log(y_in, act, self.K)
-        x_hat = self.decoder(y_in)
-        out = {'x_hat': x_hat, 'y': y, 'y_in': y_in, 'z': z, 'z_in': z_in, 'p_z': p_z, 'logp_z': logp_z,
+        out = {'y': y, 'y_in': y_in, 'z': z, 'z_in': z_in, 'p_z': p_z, 'logp_z': logp_z,
                'p_y': p_y, 'logp_y': logp_y, 'training': training}
         out.update(params)
         return out
+
+    def forward(self, x: torch.Tensor, training: bool = True, noise=None):
+        """`noise` (test hook, not in the reference): (u_z, u_y) uniform [0,1) tensors used instead
+        of torch.rand_like, in the reference's draw order (z first, Models.py:57-58)."""
+        out = self.analysis_hyperprior(x, training, noise)
+        x_hat = self.decoder(out['y_in'])
+        return {'x_hat': x_hat, **out}
 
 
 class JointAutoregressiveHierarchical(_HyperpriorContextModel):
