@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LIC_ABI_VERSION 1
+#define LIC_ABI_VERSION 2
 
 typedef void* lic_stream_t; /* hipStream_t */
 
@@ -48,7 +48,13 @@ enum lic_epilogue {
   LIC_EPI_GDN = 3,            /* n = acc + bias; out2 = n; v = aux * rsqrt(n)                 */
   LIC_EPI_IGDN = 4,           /* n = acc + bias; out2 = n; v = aux * sqrt(n)                  */
   LIC_EPI_GDN_BWD = 5,        /* v = aux * rsqrt(aux3) + 2 * aux2 * acc                       */
-  LIC_EPI_IGDN_BWD = 6        /* v = aux * sqrt(aux3)  + 2 * aux2 * acc                       */
+  LIC_EPI_IGDN_BWD = 6,       /* v = aux * sqrt(aux3)  + 2 * aux2 * acc                       */
+  /* convolution + the GDN / IGDN that follows it, in one kernel (lic_igemm_fused_gdn_supported):
+   *   x = acc + bias -> out3 (may be NULL);  n = aux2 + x^2 . aux -> out2;  out = x * rsqrt(n) | x * sqrt(n)
+   *   aux = gamma_eff^T packed by lic_pack_weight(taps=1, K=Cout, N=Cout), aux2 = beta_eff [Cout].
+   *   Bitwise identical to LIC_EPI_NONE followed by a prologue=1 / LIC_EPI_GDN contraction launch. */
+  LIC_EPI_CONV_GDN = 7,
+  LIC_EPI_CONV_IGDN = 8
   /* for every epilogue except LEAKY a non-null `res` is added to v before the store */
 };
 
@@ -89,7 +95,16 @@ typedef struct lic_igemm_desc {
   float slope;       /* LeakyReLU negative slope */
   void* workspace;   /* optional (may be NULL): lets small layers split K across workgroups */
   size_t workspace_bytes;
+  float* out3;       /* LIC_EPI_CONV_GDN / CONV_IGDN: the pre-normalisation conv output, or NULL */
+  int64_t out3_ld;
 } lic_igemm_desc;
+
+/* 1 when lic_igemm can run LIC_EPI_CONV_GDN / LIC_EPI_CONV_IGDN for these channel counts
+ * (all output channels in one full tile: Cout in {64,128,192}; Cin % 4 == 0) */
+int lic_igemm_fused_gdn_supported(int32_t Cin, int32_t Cout);
+/* 1 when fusing is also expected to be faster than two launches for this geometry (only the
+ * shape fields of `d` are read) */
+int lic_igemm_fused_gdn_preferred(const lic_igemm_desc* d);
 
 /* workspace size that enables split-K for `d` (0 = the layer is large enough not to need it) */
 size_t lic_igemm_workspace_bytes(const lic_igemm_desc* d);

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "liblic_hip.so")
 
 # enum lic_epilogue
-EPI_NONE, EPI_LEAKY, EPI_MUL_LEAKY_MASK, EPI_GDN, EPI_IGDN, EPI_GDN_BWD, EPI_IGDN_BWD = range(7)
+EPI_NONE, EPI_LEAKY, EPI_MUL_LEAKY_MASK, EPI_GDN, EPI_IGDN, EPI_GDN_BWD, EPI_IGDN_BWD, EPI_CONV_GDN, EPI_CONV_IGDN = range(9)
 FE_NPARAM = 43
 
 _vp, _i32, _i64, _f32, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_float, C.c_size_t
@@ -27,7 +27,8 @@ class IgemmDesc(C.Structure):
                 ("Ho", _i32), ("Wo", _i32), ("Cout", _i32),
                 ("kh", _i32), ("kw", _i32), ("stride", _i32), ("pad", _i32),
                 ("transposed", _i32), ("prologue", _i32), ("epilogue", _i32),
-                ("tap_mask", C.c_uint32), ("slope", _f32), ("workspace", _vp), ("workspace_bytes", _sz)]
+                ("tap_mask", C.c_uint32), ("slope", _f32), ("workspace", _vp), ("workspace_bytes", _sz),
+                ("out3", _vp), ("out3_ld", _i64)]
 
 
 class WgradDesc(C.Structure):
@@ -81,6 +82,8 @@ SIGNATURES = {
     "lic_colsum_bf16_workspace_bytes": (_sz, [_i64, _i32]),
     "lic_colsum_bf16": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _vp, _vp, _sz, _vp]),
     "lic_gdn_dnorm_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "lic_igemm_fused_gdn_supported": (C.c_int, [_i32, _i32]),
+    "lic_igemm_fused_gdn_preferred": (C.c_int, [C.POINTER(IgemmDesc)]),
     "lic_version": (C.c_int, []),
     "lic_last_hip_error": (C.c_int, []),
     "lic_arch": (C.c_char_p, []),

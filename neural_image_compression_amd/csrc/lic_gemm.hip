@@ -50,7 +50,8 @@ struct IgemmParams {
   const float* aux2;
   const float* aux3;
   const float* res;
-  long in_ld, out_ld, out2_ld, aux_ld, aux2_ld, aux3_ld, res_ld;
+  float* out3;
+  long in_ld, out_ld, out2_ld, aux_ld, aux2_ld, aux3_ld, res_ld, out3_ld;
   int B, Hi, Wi, Cin, Ho, Wo, Cout;
   int kw, stride, pad, transposed, prologue, epilogue;
   float slope;
@@ -63,6 +64,7 @@ struct IgemmParams {
   int cps;     // chunks per split
   float* slabs;  // [ksplit][B*Ho*Wo][Cout] fp32
   int MT, NT;  // tiles in M (max over phases) and N
+  int bm_unfused;  // host-side note: the M tile the same launch would use without a fused GDN
   int ntaps[4];
   int Hq[4], Wq[4];
   FastDiv dHW[4], dW[4];  // divide by Hq*Wq and by Wq
@@ -75,14 +77,19 @@ constexpr int IG_LDA = IG_BK + 4;
 // FULLN: every wave of every workgroup has all its TN column tiles live (Npad % (64*TN) == 0), so
 // the MFMA block is branch-free.  (With the scalar branches of the ragged variant hipcc shuffles
 // accumulators through v_accvgpr_read/mov at the joins: ~2 extra AGPR moves per MFMA.)
-template <int BM, int TN, bool VEC, bool FULLN>
+// FUSE (BM = 64, one N tile covering all channels): the GDN / IGDN that follows the convolution
+// runs in this kernel's epilogue -- see the block after the K loop.
+template <int BM, int TN, bool VEC, bool FULLN, bool FUSE = false>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   constexpr int BN = 64 * TN;
   constexpr int WM = BM / 2, WN = BN / 2;  // 2x2 waves
   constexpr int TM = WM / 32;              // MFMA tiles per wave in M
   constexpr int APASS = BM / 64;           // float4 A loads per thread per chunk
   // A double buffer; after the K loop the same memory stages 32x32 output tiles (one per wave)
-  constexpr int SA_FLOATS = (2 * BM * IG_LDA > 4 * 1024) ? 2 * BM * IG_LDA : 4 * 1024;
+  constexpr int SA_MAIN = (2 * BM * IG_LDA > 4 * 1024) ? 2 * BM * IG_LDA : 4 * 1024;
+  // fused GDN epilogue: x tile [64][BN+4] + one 32x32 patch per wave
+  constexpr int SA_FLOATS = (FUSE && 64 * (BN + 4) + 4096 > SA_MAIN) ? 64 * (BN + 4) + 4096 : SA_MAIN;
+  static_assert(!FUSE || (VEC && FULLN), "fused GDN epilogue: float4 gathers, full N");
   __shared__ __attribute__((aligned(16))) float smem[SA_FLOATS];
   float(*sA)[BM * IG_LDA] = reinterpret_cast<float(*)[BM * IG_LDA]>(smem);
 
@@ -317,6 +324,117 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     }
   }
 
+
+  // ---- fused GDN / IGDN (LIC_EPI_CONV_GDN / LIC_EPI_CONV_IGDN) ----------------------------------
+  // The tile holds ALL channels of its 64 pixels, so the normalisation pool
+  //   norm[p][i] = beta[i] + sum_j gamma[i][j] * x[p][j]^2,   y = x * rsqrt(norm)  (sqrt for IGDN)
+  // is a second, short MFMA loop over the tile itself: x = acc + bias goes to LDS ([64][BN+4], the
+  // +4 shifts consecutive rows by one 16-byte bank slot), each wave contracts its own 32 rows
+  // against the packed gamma^T panel (p.aux, read from L2 exactly like the conv weights) in the
+  // same chunk / k order as the stand-alone contraction launch, so the results are bitwise those of
+  // conv -> gdn run as two kernels -- minus one full read of x and one launch per layer.
+  if constexpr (FUSE) {
+    constexpr int LDX = BN + 4;
+    constexpr int NCH = BN / IG_BK;
+    float* xt = smem;  // [64][LDX]: 32 rows per wave row; 128-row tiles take two passes (a = 0, 1)
+    const int xr0 = (wave >> 1) * 32;
+    const float* glane = p.aux + ((long)(wn0 >> 5) * 512 + lane * 4);
+    const float* xrow = xt + (xr0 + li) * LDX + lh * 8;
+    const int c4 = (lane & 7) * 4, r8 = lane >> 3;
+    const bool inv = p.epilogue == LIC_EPI_CONV_IGDN;
+    // (the K loop ended with a barrier: the A buffers are dead)
+#pragma unroll
+    for (int a = 0; a < TM; ++a) {
+      if (a > 0) __syncthreads();  // the previous pass is done with the tile
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        const int col = wn0 + b * 32 + li;
+        const float bv = p.bias ? p.bias[col] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          xt[(xr0 + (r & 3) + 8 * (r >> 2) + 4 * lh) * LDX + col] = acc[a][b][r] + bv;
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
+      f32x4 g0[TN][2], g1[TN][2];
+      auto load_g = [&](f32x4 (&rg)[TN][2], int c) {
+        const float* src = glane + (long)(c < NCH ? c : NCH - 1) * p.Npad * IG_BK;
+#pragma unroll
+        for (int b = 0; b < TN; ++b) {
+          rg[b][0] = *reinterpret_cast<const f32x4*>(src + b * 512);
+          rg[b][1] = *reinterpret_cast<const f32x4*>(src + b * 512 + 256);
+        }
+      };
+      auto pool = [&](int c, const f32x4 (&rg)[TN][2]) {
+        f32x4 a0 = *reinterpret_cast<const f32x4*>(xrow + c * IG_BK);
+        f32x4 a1 = *reinterpret_cast<const f32x4*>(xrow + c * IG_BK + 4);
+        a0 = a0 * a0;
+        a1 = a1 * a1;
+#pragma unroll
+        for (int t = 0; t < 8; ++t)
+#pragma unroll
+          for (int b = 0; b < TN; ++b)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32((t < 4 ? a0 : a1)[t & 3], rg[b][t >> 2][t & 3],
+                                                              acc[a][b], 0, 0, 0);
+      };
+      load_g(g0, 0);
+#pragma unroll 1
+      for (int c = 0; c < NCH; c += 2) {
+        load_g(g1, c + 1);
+        pool(c, g0);
+        load_g(g0, c + 2);
+        pool(c + 1, g1);
+      }
+      // Finish in the 16-byte layout: each 32x32 pool tile goes through a wave-private LDS patch so
+      // that a lane owns 4 consecutive channels of a row, meets x there, and stores x, norm and y.
+      long opix[4];
+      bool rok[4];
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int prow = m0 + wm0 + a * 32 + it * 8 + r8;
+        rok[it] = prow < P;
+        const int pr = rok[it] ? prow : 0;
+        if (p.nphase > 1) {
+          const int bb = fdiv(pr, p.dHW[phase]);
+          const int rem = pr - bb * Hq * Wq;
+          const int i = fdiv(rem, p.dW[phase]), jj = rem - i * Wq;
+          opix[it] = ((long)bb * p.Ho + i * sph + py) * p.Wo + jj * sph + px;
+        } else {
+          opix[it] = pr;
+        }
+      }
+      float* stg = smem + 64 * LDX + wave * 1024;
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = acc[a][b][r];
+        __builtin_amdgcn_wave_barrier();
+        const int col = wn0 + b * 32 + c4;
+        const f32x4 be4 = *reinterpret_cast<const f32x4*>(p.aux2 + col);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          if (!rok[it]) continue;
+          const int rr = it * 8 + r8;
+          const f32x4 n4 = *reinterpret_cast<const f32x4*>(&stg[rr * 32 + c4]) + be4;
+          const f32x4 x4 = *reinterpret_cast<const f32x4*>(&xt[(xr0 + rr) * LDX + col]);
+          f32x4 y4;
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            y4[e] = x4[e] * (inv ? __builtin_amdgcn_sqrtf(n4[e]) : __builtin_amdgcn_rsqf(n4[e]));
+          if (p.out3) *reinterpret_cast<f32x4*>(p.out3 + opix[it] * p.out3_ld + col) = x4;
+          *reinterpret_cast<f32x4*>(p.out2 + opix[it] * p.out2_ld + col) = n4;
+          *reinterpret_cast<f32x4*>(p.out + opix[it] * p.out_ld + col) = y4;
+        }
+        __builtin_amdgcn_wave_barrier();
+      }
+    }
+    return;
+  }
+
   // ---- epilogue -------------------------------------------------------------------------------
   if (p.ksplit > 1) {  // raw partial sums -> slab [ks][pixel][Cout]; igemm_finish_kernel does the rest
     float* slab = p.slabs + (long)ks * ((long)p.B * p.Ho * p.Wo) * p.Cout;
@@ -506,6 +624,11 @@ __global__ __launch_bounds__(256) void igemm_finish_kernel(const float* slabs, i
   }
 }
 
+// conv + GDN fusion needs all channels in one full N tile and float4 gathers
+LIC_EXPORT int lic_igemm_fused_gdn_supported(int32_t Cin, int32_t Cout) {
+  return (Cout == 64 || Cout == 128 || Cout == 192) && Cin > 0 && Cin % 4 == 0;
+}
+
 // fills the kernel parameter block; returns LIC_OK, or 1 when there is nothing to launch
 static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& TN, long& nwg,
                          int64_t& live_macs) {
@@ -521,6 +644,12 @@ static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& 
   if ((epi == LIC_EPI_GDN_BWD || epi == LIC_EPI_IGDN_BWD) && (!d->aux || !d->aux2 || !d->aux3))
     return LIC_ERR_INVALID;
   if (epi == LIC_EPI_LEAKY && d->res && !d->out2) return LIC_ERR_INVALID;
+  const bool fuse = (epi == LIC_EPI_CONV_GDN || epi == LIC_EPI_CONV_IGDN);
+  if (fuse) {
+    if (!d->aux || !d->aux2 || !d->out2 || d->res || d->prologue) return LIC_ERR_INVALID;
+    if (!lic_igemm_fused_gdn_supported(d->Cin, d->Cout)) return LIC_ERR_UNSUPPORTED;
+    if (!aligned16(d->aux)) return LIC_ERR_INVALID;
+  }
 
   p.in = d->in;
   p.w = d->w;
@@ -531,6 +660,8 @@ static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& 
   p.aux2 = d->aux2;
   p.aux3 = d->aux3;
   p.res = d->res;
+  p.out3 = fuse ? d->out3 : nullptr;
+  p.out3_ld = d->out3_ld;
   p.in_ld = d->in_ld;
   p.out_ld = d->out_ld;
   p.out2_ld = d->out2_ld;
@@ -560,6 +691,10 @@ static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& 
     p.vec_out = (d->Cout % 4 == 0) && okp(d->out, d->out_ld) && okp(d->out2, d->out2_ld) &&
                 okp(d->aux, d->aux_ld) && okp(d->aux2, d->aux2_ld) && okp(d->aux3, d->aux3_ld) &&
                 okp(d->res, d->res_ld) && okp(d->bias, 4);
+    if (fuse) {  // aux / aux2 are the packed gamma panel and beta here, not activations
+      p.vec_out = okp(d->out, d->out_ld) && okp(d->out2, d->out2_ld) && okp(d->out3, d->out3_ld);
+      if (!p.vec || !p.vec_out) return LIC_ERR_UNSUPPORTED;
+    }
   }
   const uint32_t mask = d->tap_mask ? d->tap_mask : 0xFFFFFFFFu;
   p.nphase = (p.transposed && d->stride > 1) ? d->stride * d->stride : 1;
@@ -630,6 +765,16 @@ static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& 
     }
   BM = cand[best][0];
   TN = cand[best][1];
+  // One N tile spanning every channel, 64 rows.  (A 128-row fused variant was built and measured:
+  // all workgroups of a launch reach their epilogue together, so the pool is not hidden behind other
+  // workgroups' K loops, and the big layers came out 15-20 % slower than conv + a separate GDN
+  // launch; lic_igemm_fused_gdn_preferred tells the caller when fusing pays.)
+  const int BM_unfused = BM;
+  if (fuse) {
+    TN = p.Npad / 64;
+    BM = 64;
+  }
+  p.bm_unfused = BM_unfused;
   p.NT = (p.Npad + 64 * TN - 1) / (64 * TN);
   p.MT = (int)((maxP + BM - 1) / BM);
   nwg = (long)p.MT * p.NT * p.nphase;
@@ -644,7 +789,7 @@ static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& 
   // The split factor depends only on per-image geometry (never on the batch size), so an image's
   // result does not depend on which batch it is computed in (bitwise batch-split invariance).
   const long t_img = (((long)d->Ho * d->Wo + 63) / 64) * ((p.Npad + 63) / 64);
-  if (simple_epi && d->workspace && t_img < 40 && max_chunks >= 16) {
+  if (simple_epi && !fuse && d->workspace && t_img < 40 && max_chunks >= 16) {
     long S = (40 + t_img - 1) / t_img;
     if (S > max_chunks / 8) S = max_chunks / 8;  // at least 8 chunks per split
     if (S > 32) S = 32;
@@ -668,7 +813,7 @@ LIC_EXPORT size_t lic_igemm_workspace_bytes(const lic_igemm_desc* d) {
   q.in = q.w = dummy;
   q.out = dummy;
   q.bias = q.aux = q.aux2 = q.aux3 = q.res = nullptr;
-  q.out2 = nullptr;
+  q.out2 = q.out3 = nullptr;
   if (q.epilogue != LIC_EPI_NONE && q.epilogue != LIC_EPI_LEAKY) return 0;
   q.workspace = dummy;
   q.workspace_bytes = ~(size_t)0;
@@ -678,6 +823,29 @@ LIC_EXPORT size_t lic_igemm_workspace_bytes(const lic_igemm_desc* d) {
   int64_t macs = 0;
   if (igemm_prepare(&q, p, bm, tn, nwg, macs) != LIC_OK || p.ksplit <= 1) return 0;
   return (size_t)p.ksplit * d->B * d->Ho * d->Wo * d->Cout * sizeof(float);
+}
+
+// 1 when the fused conv+GDN launch is expected to beat conv followed by a GDN contraction launch:
+// layers whose plain launch would use 64-row tiles anyway (measured on MI355X: RGB stem -12 %,
+// 32x32 / 64x64-output layers -0..7 %; the 128-row-tile layers lose 15-20 % when fused)
+LIC_EXPORT int lic_igemm_fused_gdn_preferred(const lic_igemm_desc* d) {
+  if (!d || !lic_igemm_fused_gdn_supported(d->Cin, d->Cout)) return 0;
+  lic_igemm_desc q = *d;
+  static float dummy[4] __attribute__((aligned(16)));
+  q.in = q.w = q.aux = q.aux2 = dummy;
+  q.out = q.out2 = dummy;
+  q.out3 = nullptr;
+  q.bias = q.aux3 = q.res = nullptr;
+  q.workspace = nullptr;
+  q.workspace_bytes = 0;
+  q.prologue = 0;
+  q.epilogue = LIC_EPI_CONV_GDN;
+  IgemmParams p;
+  int bm = 0, tn = 0;
+  long nwg = 0;
+  int64_t macs = 0;
+  if (igemm_prepare(&q, p, bm, tn, nwg, macs) != LIC_OK) return 0;
+  return p.bm_unfused == 64 ? 1 : 0;
 }
 
 LIC_EXPORT int lic_igemm_plan(const lic_igemm_desc* d, int32_t* BM, int32_t* BN, int64_t* live_macs) {
@@ -711,7 +879,14 @@ LIC_EXPORT int lic_igemm(const lic_igemm_desc* d, lic_stream_t stream) {
     else                                                                                \
       hipLaunchKernelGGL((igemm_kernel<bm, tn, true, false>), grid, block, 0, s, p);    \
   } while (0)
-  if (!p.vec)  // odd channel counts / unaligned views: scalar-load variant, one tile shape
+  if (p.epilogue == LIC_EPI_CONV_GDN || p.epilogue == LIC_EPI_CONV_IGDN) {
+    if (TN == 3)
+      hipLaunchKernelGGL((igemm_kernel<64, 3, true, true, true>), grid, block, 0, s, p);
+    else if (TN == 2)
+      hipLaunchKernelGGL((igemm_kernel<64, 2, true, true, true>), grid, block, 0, s, p);
+    else
+      hipLaunchKernelGGL((igemm_kernel<64, 1, true, true, true>), grid, block, 0, s, p);
+  } else if (!p.vec)  // odd channel counts / unaligned views: scalar-load variant, one tile shape
     hipLaunchKernelGGL((igemm_kernel<64, 1, false, false>), grid, block, 0, s, p);
   else if (BM == 128 && TN == 3)
     LIC_IGEMM_LAUNCH(128, 3);

@@ -94,19 +94,21 @@ def _pack_conv_weight(w: torch.Tensor, transposed_weight: bool, for_dgrad: bool)
 
 def _igemm(inp, w_packed, out, *, B, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, pad, transposed,
            bias=None, prologue=0, epilogue=L.EPI_NONE, slope=0.01, tap_mask=0, out2=None, aux=None,
-           aux2=None, aux3=None, res=None, in_ld=None, out_ld=None):
+           aux2=None, aux3=None, res=None, in_ld=None, out_ld=None, out3=None):
     d = L.IgemmDesc()
     d.in_, d.w, d.bias, d.out, d.out2 = _ptr(inp), _ptr(w_packed), _ptr(bias), _ptr(out), _ptr(out2)
     d.aux, d.aux2, d.aux3, d.res = _ptr(aux), _ptr(aux2), _ptr(aux3), _ptr(res)
     d.in_ld = Cin if in_ld is None else in_ld
     d.out_ld = Cout if out_ld is None else out_ld
-    d.out2_ld = d.aux_ld = d.aux2_ld = d.aux3_ld = d.res_ld = Cout
+    d.out2_ld = d.aux_ld = d.aux2_ld = d.aux3_ld = d.res_ld = d.out3_ld = Cout
+    d.out3 = _ptr(out3)
     d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout = B, Hi, Wi, Cin, Ho, Wo, Cout
     d.kh, d.kw, d.stride, d.pad = kh, kw, stride, pad
     d.transposed, d.prologue, d.epilogue = int(transposed), prologue, epilogue
     d.tap_mask, d.slope = tap_mask, slope
     lib = L.load()
     ws = None
+    fused = epilogue in (L.EPI_CONV_GDN, L.EPI_CONV_IGDN)
     if Ho * Wo <= 1024 and out2 is None and res is None:  # latent-side layers: allow split-K
         nbytes = lib.lic_igemm_workspace_bytes(C.byref(d))
         if nbytes:
@@ -126,7 +128,12 @@ def _igemm(inp, w_packed, out, *, B, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, 
     tn = bn.value // 64
     full = vec and ((Cout + 31) // 32 * 32) % (64 * tn) == 0
     name = f"igemm_kernel<{bm.value}, {tn}, {str(vec).lower()}, {str(full).lower()}>"  # as rocprofv3 prints it
-    PROFILE.append((name, 2 * macs.value, act_bytes, e0, e1))
+    flops = 2 * macs.value
+    if fused:  # conv + the channel pool of the GDN that follows it
+        name = f"igemm_kernel<{bm.value}, {tn}, true, true, true>"
+        flops += 2 * B * Ho * Wo * Cout * Cout
+        act_bytes += 4 * 2 * B * Ho * Wo * Cout
+    PROFILE.append((name, flops, act_bytes, e0, e1))
 
 
 def _wgrad(p, g, dst, *, B, Hs, Ws, Cp, Hl, Wl, Cg, kh, kw, stride, pad, g_is_row, dst_sm, dst_sn,
@@ -214,29 +221,37 @@ class _ConvFn(torch.autograd.Function):
         g = _nhwc(gy)
         if leaky:
             g = _leaky_bwd(yh, g, slope)
-        B, Hi, Wi, Cin = xh.shape
-        _, Ho, Wo, Cout = g.shape
-        kh, kw = weight.shape[2], weight.shape[3]
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            wp = _pack_conv_weight(weight, transposed, for_dgrad=True)
-            dxh = torch.empty_like(xh)
-            # the data gradient of a conv is the transposed gather and vice versa
-            _igemm(g, wp, dxh, B=B, Hi=Ho, Wi=Wo, Cin=Cout, Ho=Hi, Wo=Wi, Cout=Cin, kh=kh, kw=kw,
-                   stride=stride, pad=pad, transposed=not transposed, tap_mask=tap_mask)
-            dx = _nchw_view(dxh)
-        if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
-            taps = kh * kw
-            if transposed:  # weight [Cin,Cout,kh,kw]; small grid = input, gathered = grad
-                _wgrad(xh, g, dw, B=B, Hs=Hi, Ws=Wi, Cp=Cin, Hl=Ho, Wl=Wo, Cg=Cout, kh=kh, kw=kw,
-                       stride=stride, pad=pad, g_is_row=False, dst_sm=Cout * taps, dst_sn=taps, dst_stap=1)
-            else:  # weight [Cout,Cin,kh,kw]; small grid = output grad, gathered = input
-                _wgrad(g, xh, dw, B=B, Hs=Ho, Ws=Wo, Cp=Cout, Hl=Hi, Wl=Wi, Cg=Cin, kh=kh, kw=kw,
-                       stride=stride, pad=pad, g_is_row=True, dst_sm=taps, dst_sn=Cin * taps, dst_stap=1)
-        if has_bias and ctx.needs_input_grad[2]:
-            db = _colsum(g, B * Ho * Wo, Cout)
+        dx, dw, db = _conv_backward(xh, weight, g, stride, pad, transposed, tap_mask,
+                                    ctx.needs_input_grad[0], ctx.needs_input_grad[1],
+                                    has_bias and ctx.needs_input_grad[2])
         return dx, dw, db, None, None, None, None, None, None, None, (gy if has_res else None)
+
+
+def _conv_backward(xh, weight, g, stride, pad, transposed, tap_mask, need_dx, need_dw, need_db):
+    """Input / weight / bias gradients of a conv (or transposed conv) from the NHWC output gradient."""
+    B, Hi, Wi, Cin = xh.shape
+    _, Ho, Wo, Cout = g.shape
+    kh, kw = weight.shape[2], weight.shape[3]
+    dx = dw = db = None
+    if need_dx:
+        wp = _pack_conv_weight(weight, transposed, for_dgrad=True)
+        dxh = torch.empty_like(xh)
+        # the data gradient of a conv is the transposed gather and vice versa
+        _igemm(g, wp, dxh, B=B, Hi=Ho, Wi=Wo, Cin=Cout, Ho=Hi, Wo=Wi, Cout=Cin, kh=kh, kw=kw,
+               stride=stride, pad=pad, transposed=not transposed, tap_mask=tap_mask)
+        dx = _nchw_view(dxh)
+    if need_dw:
+        dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+        taps = kh * kw
+        if transposed:  # weight [Cin,Cout,kh,kw]; small grid = input, gathered = grad
+            _wgrad(xh, g, dw, B=B, Hs=Hi, Ws=Wi, Cp=Cin, Hl=Ho, Wl=Wo, Cg=Cout, kh=kh, kw=kw,
+                   stride=stride, pad=pad, g_is_row=False, dst_sm=Cout * taps, dst_sn=taps, dst_stap=1)
+        else:  # weight [Cout,Cin,kh,kw]; small grid = output grad, gathered = input
+            _wgrad(g, xh, dw, B=B, Hs=Ho, Ws=Wo, Cp=Cout, Hl=Hi, Wl=Wi, Cg=Cin, kh=kh, kw=kw,
+                   stride=stride, pad=pad, g_is_row=True, dst_sm=taps, dst_sn=Cin * taps, dst_stap=1)
+    if need_db:
+        db = _colsum(g, B * Ho * Wo, Cout)
+    return dx, dw, db
 
 
 def conv2d(x, weight, bias, stride=1, padding=0, leaky=False, slope=0.01, tap_mask=0, residual=None):
@@ -255,6 +270,51 @@ def _kpad(kh, kw, c):
     return (kh * kw * c + 3) // 4 * 4
 
 
+def _image_conv_columns(xh, weight, stride, pad):
+    """im2col of the few-channel input + the [Kp][Cout] weight matrix; returns (col, wp, Ho, Wo, Kp)."""
+    B, Hi, Wi, Cin = xh.shape
+    Cout, _, kh, kw = weight.shape
+    Ho, Wo = conv_out_size(Hi, Wi, kh, stride, pad, False)
+    Kp = _kpad(kh, kw, Cin)
+    P = B * Ho * Wo
+    col = torch.empty((P, Kp), device=xh.device, dtype=torch.float32)
+    L.check(L.load().lic_im2col(_ptr(xh), _ptr(col), B, Hi, Wi, Cin, Ho, Wo, kh, kw, stride, pad, Kp,
+                                _stream()), "lic_im2col")
+    taps = kh * kw
+    wp = torch.zeros((Kp, Cout), device=xh.device, dtype=torch.float32)
+    # wp[tap*Cin + c][co] = w[co][c][tap]
+    _permute3(weight.contiguous(), wp, (taps, Cin, Cout), (1, taps, Cin * taps), (Cin * Cout, Cout, 1))
+    return col, wp, Ho, Wo, Kp
+
+
+def _image_conv_backward(col, weight, g, stride, pad, in_shape, need_dx, need_dw, need_db):
+    B, Hi, Wi, Cin = in_shape
+    _, Ho, Wo, Cout = g.shape
+    _, _, kh, kw = weight.shape
+    taps, Kp, P = kh * kw, col.shape[1], B * Ho * Wo
+    lib = L.load()
+    dx = dw = db = None
+    if need_dx:
+        wpT = torch.zeros((Cout, Kp), device=g.device, dtype=torch.float32)
+        _permute3(weight.contiguous(), wpT, (Cout, Cin, taps), (Cin * taps, taps, 1), (Kp, 1, Cin))
+        dcol = torch.empty((P, Kp), device=g.device, dtype=torch.float32)
+        _igemm(g, _pack_dense(wpT), dcol, B=1, Hi=1, Wi=P, Cin=Cout, Ho=1, Wo=P, Cout=Kp, kh=1, kw=1, stride=1,
+               pad=0, transposed=False)
+        dxh = torch.empty((B, Hi, Wi, Cin), device=g.device, dtype=torch.float32)
+        L.check(lib.lic_col2im(_ptr(dcol), None, _ptr(dxh), B, Ho, Wo, Cin, Hi, Wi, kh, kw, stride,
+                               pad, Kp, _stream()), "lic_col2im")
+        dx = _nchw_view(dxh)
+    if need_dw:
+        tmp = torch.empty((Kp, Cout), device=g.device, dtype=torch.float32)
+        _wgrad(col, g, tmp, B=1, Hs=1, Ws=P, Cp=Kp, Hl=1, Wl=P, Cg=Cout, kh=1, kw=1, stride=1, pad=0,
+               g_is_row=False, dst_sm=Cout, dst_sn=1, dst_stap=0)
+        dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+        _permute3(tmp, dw, (taps, Cin, Cout), (Cin * Cout, Cout, 1), (1, taps, Cin * taps))
+    if need_db:
+        db = _colsum(g, P, Cout)
+    return dx, dw, db
+
+
 class _ImageConvFn(torch.autograd.Function):
     """nn.Conv2d whose INPUT has few channels (the RGB stem: Components.py:10; Layers.py:38,43
     inside Encoder3x3's first block).  im2col (HBM-bound) + MFMA GEMM with K = kh*kw*C."""
@@ -263,58 +323,63 @@ class _ImageConvFn(torch.autograd.Function):
     def forward(ctx, x, weight, bias, stride, pad, leaky, slope):
         _require_cuda(x, weight, bias)
         xh = _nhwc(x)
-        B, Hi, Wi, Cin = xh.shape
-        Cout, _, kh, kw = weight.shape
-        Ho, Wo = conv_out_size(Hi, Wi, kh, stride, pad, False)
-        Kp = _kpad(kh, kw, Cin)
+        B = xh.shape[0]
+        Cout = weight.shape[0]
+        col, wp, Ho, Wo, Kp = _image_conv_columns(xh, weight, stride, pad)
         P = B * Ho * Wo
-        lib = L.load()
-        col = torch.empty((P, Kp), device=x.device, dtype=torch.float32)
-        L.check(lib.lic_im2col(_ptr(xh), _ptr(col), B, Hi, Wi, Cin, Ho, Wo, kh, kw, stride, pad, Kp,
-                               _stream()), "lic_im2col")
-        taps = kh * kw
-        wp = torch.zeros((Kp, Cout), device=x.device, dtype=torch.float32)
-        # wp[tap*Cin + c][co] = w[co][c][tap]
-        _permute3(weight.contiguous(), wp, (taps, Cin, Cout), (1, taps, Cin * taps), (Cin * Cout, Cout, 1))
         out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
         _igemm(col, _pack_dense(wp), out, B=1, Hi=1, Wi=P, Cin=Kp, Ho=1, Wo=P, Cout=Cout, kh=1, kw=1, stride=1,
                pad=0, transposed=False, bias=bias, epilogue=L.EPI_LEAKY if leaky else L.EPI_NONE,
                slope=slope)
         ctx.save_for_backward(col, weight, out if leaky else None)
-        ctx.cfg = (stride, pad, leaky, slope, (B, Hi, Wi, Cin), bias is not None)
+        ctx.cfg = (stride, pad, leaky, slope, tuple(xh.shape), bias is not None)
         return _nchw_view(out)
 
     @staticmethod
     def backward(ctx, gy):
         col, weight, yh = ctx.saved_tensors
-        stride, pad, leaky, slope, (B, Hi, Wi, Cin), has_bias = ctx.cfg
+        stride, pad, leaky, slope, in_shape, has_bias = ctx.cfg
         g = _nhwc(gy)
         if leaky:
             g = _leaky_bwd(yh, g, slope)
-        _, Ho, Wo, Cout = g.shape
-        _, _, kh, kw = weight.shape
-        taps, Kp, P = kh * kw, col.shape[1], B * Ho * Wo
-        lib = L.load()
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            wpT = torch.zeros((Cout, Kp), device=g.device, dtype=torch.float32)
-            _permute3(weight.contiguous(), wpT, (Cout, Cin, taps), (Cin * taps, taps, 1), (Kp, 1, Cin))
-            dcol = torch.empty((P, Kp), device=g.device, dtype=torch.float32)
-            _igemm(g, _pack_dense(wpT), dcol, B=1, Hi=1, Wi=P, Cin=Cout, Ho=1, Wo=P, Cout=Kp, kh=1, kw=1, stride=1,
-                   pad=0, transposed=False)
-            dxh = torch.empty((B, Hi, Wi, Cin), device=g.device, dtype=torch.float32)
-            L.check(lib.lic_col2im(_ptr(dcol), None, _ptr(dxh), B, Ho, Wo, Cin, Hi, Wi, kh, kw, stride,
-                                   pad, Kp, _stream()), "lic_col2im")
-            dx = _nchw_view(dxh)
-        if ctx.needs_input_grad[1]:
-            tmp = torch.empty((Kp, Cout), device=g.device, dtype=torch.float32)
-            _wgrad(col, g, tmp, B=1, Hs=1, Ws=P, Cp=Kp, Hl=1, Wl=P, Cg=Cout, kh=1, kw=1, stride=1, pad=0,
-                   g_is_row=False, dst_sm=Cout, dst_sn=1, dst_stap=0)
-            dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
-            _permute3(tmp, dw, (taps, Cin, Cout), (Cin * Cout, Cout, 1), (1, taps, Cin * taps))
-        if has_bias and ctx.needs_input_grad[2]:
-            db = _colsum(g, P, Cout)
+        dx, dw, db = _image_conv_backward(col, weight, g, stride, pad, in_shape, ctx.needs_input_grad[0],
+                                          ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2])
         return dx, dw, db, None, None, None, None
+
+
+class _ImageConvGDNFn(torch.autograd.Function):
+    """The RGB stem and the GDN behind it (Components.py:10-11) with the pool fused into the GEMM."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, beta, gamma, stride, pad, inverse, beta_bound, gamma_bound, pedestal):
+        _require_cuda(x, weight, bias, beta, gamma)
+        xh = _nhwc(x)
+        B = xh.shape[0]
+        Cout = weight.shape[0]
+        col, wp, Ho, Wo, Kp = _image_conv_columns(xh, weight, stride, pad)
+        P = B * Ho * Wo
+        beta_c, gamma_c, beta_e, gamma_e = _gdn_reparam(beta, gamma, beta_bound, gamma_bound, pedestal)
+        gT = _pack(gamma_e, 1, Cout, Cout, 0, 1, Cout)
+        conv_out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+        norm = torch.empty_like(conv_out)
+        y = torch.empty_like(conv_out)
+        _igemm(col, _pack_dense(wp), y, B=1, Hi=1, Wi=P, Cin=Kp, Ho=1, Wo=P, Cout=Cout, kh=1, kw=1, stride=1,
+               pad=0, transposed=False, bias=bias, epilogue=L.EPI_CONV_IGDN if inverse else L.EPI_CONV_GDN,
+               out2=norm, out3=conv_out, aux=gT, aux2=beta_e)
+        ctx.save_for_backward(col, weight, conv_out, norm, gamma_e, beta_c, gamma_c)
+        ctx.cfg = (stride, pad, tuple(xh.shape), inverse, beta_bound, gamma_bound, bias is not None)
+        return _nchw_view(y)
+
+    @staticmethod
+    def backward(ctx, gy):
+        col, weight, conv_out, norm, gamma_e, beta_c, gamma_c = ctx.saved_tensors
+        stride, pad, in_shape, inverse, beta_bound, gamma_bound, has_bias = ctx.cfg
+        need = ctx.needs_input_grad
+        g_conv, dbeta, dgamma = _gdn_backward(conv_out, norm, gamma_e, beta_c, gamma_c, _nhwc(gy), inverse,
+                                              beta_bound, gamma_bound, True, need[3], need[4])
+        dx, dw, db = _image_conv_backward(col, weight, g_conv, stride, pad, in_shape, need[0], need[1],
+                                          has_bias and need[2])
+        return dx, dw, db, dbeta, dgamma, None, None, None, None, None, None
 
 
 class _ImageConvTFn(torch.autograd.Function):
@@ -417,13 +482,7 @@ class _GDNFn(torch.autograd.Function):
         lib = L.load()
         xh = _nhwc(x)
         B, H, W, Cc = xh.shape
-        beta_c, gamma_c = beta.contiguous(), gamma.contiguous()
-        beta_e = torch.empty_like(beta_c)
-        gamma_e = torch.empty_like(gamma_c)
-        L.check(lib.lic_gdn_reparam(_ptr(beta_c), _ptr(beta_e), Cc, beta_bound, pedestal, _stream()),
-                "lic_gdn_reparam")
-        L.check(lib.lic_gdn_reparam(_ptr(gamma_c), _ptr(gamma_e), Cc * Cc, gamma_bound, pedestal,
-                                    _stream()), "lic_gdn_reparam")
+        beta_c, gamma_c, beta_e, gamma_e = _gdn_reparam(beta, gamma, beta_bound, gamma_bound, pedestal)
         gT = _pack(gamma_e, 1, Cc, Cc, 0, 1, Cc)  # B operand [k=j][n=i] = gamma_e[i][j]
         out = torch.empty_like(xh)
         norm = torch.empty_like(xh)
@@ -440,34 +499,127 @@ class _GDNFn(torch.autograd.Function):
     def backward(ctx, gy):
         xh, norm, gamma_e, beta_c, gamma_c = ctx.saved_tensors
         inverse, beta_bound, gamma_bound, has_res = ctx.cfg
-        lib = L.load()
-        g = _nhwc(gy)
-        B, H, W, Cc = xh.shape
-        P = B * H * W
-        t = torch.empty_like(xh)
-        L.check(lib.lic_gdn_dnorm(_ptr(g), _ptr(xh), _ptr(norm), _ptr(t), xh.numel(), int(inverse),
-                                  _stream()), "lic_gdn_dnorm")
-        dx = dbeta = dgamma = None
-        if ctx.needs_input_grad[0]:
-            dxh = torch.empty_like(xh)
-            _igemm(t, _pack_dense(gamma_e), dxh, B=1, Hi=1, Wi=P, Cin=Cc, Ho=1, Wo=P, Cout=Cc, kh=1, kw=1, stride=1,
-                   pad=0, transposed=False, epilogue=L.EPI_IGDN_BWD if inverse else L.EPI_GDN_BWD,
-                   aux=g, aux2=xh, aux3=norm)
-            dx = _nchw_view(dxh)
-        if ctx.needs_input_grad[1]:
-            dbe = _colsum(t, P, Cc)
-            dbeta = torch.empty_like(beta_c)
-            L.check(lib.lic_gdn_reparam_bwd(_ptr(beta_c), _ptr(dbe), _ptr(dbeta), Cc, beta_bound,
-                                            _stream()), "lic_gdn_reparam_bwd")
-        if ctx.needs_input_grad[2]:
-            dge = torch.empty_like(gamma_e)
-            _wgrad(t, xh, dge, B=1, Hs=1, Ws=P, Cp=Cc, Hl=1, Wl=P, Cg=Cc, kh=1, kw=1, stride=1, pad=0,
-                   g_is_row=False, dst_sm=Cc, dst_sn=1, dst_stap=0, sq_g=1)
-            dgamma = torch.empty_like(gamma_c)
-            L.check(lib.lic_gdn_reparam_bwd(_ptr(gamma_c), _ptr(dge), _ptr(dgamma), Cc * Cc, gamma_bound,
-                                            _stream()), "lic_gdn_reparam_bwd")
+        dxh, dbeta, dgamma = _gdn_backward(xh, norm, gamma_e, beta_c, gamma_c, _nhwc(gy), inverse, beta_bound,
+                                           gamma_bound, *ctx.needs_input_grad[:3])
         dres = gy if has_res else None
-        return dx, dbeta, dgamma, None, None, None, None, dres
+        return (None if dxh is None else _nchw_view(dxh)), dbeta, dgamma, None, None, None, None, dres
+
+
+def _gdn_reparam(beta, gamma, beta_bound, gamma_bound, pedestal):
+    """beta_eff [C], gamma_eff [C,C] of the non-negative re-parametrisation."""
+    lib = L.load()
+    Cc = beta.numel()
+    beta_c, gamma_c = beta.contiguous(), gamma.contiguous()
+    beta_e = torch.empty_like(beta_c)
+    gamma_e = torch.empty_like(gamma_c)
+    L.check(lib.lic_gdn_reparam(_ptr(beta_c), _ptr(beta_e), Cc, beta_bound, pedestal, _stream()),
+            "lic_gdn_reparam")
+    L.check(lib.lic_gdn_reparam(_ptr(gamma_c), _ptr(gamma_e), Cc * Cc, gamma_bound, pedestal,
+                                _stream()), "lic_gdn_reparam")
+    return beta_c, gamma_c, beta_e, gamma_e
+
+
+def _gdn_backward(xh, norm, gamma_e, beta_c, gamma_c, g, inverse, beta_bound, gamma_bound, need_dx, need_dbeta,
+                  need_dgamma):
+    """GDN / IGDN backward from the saved input x and pool `norm`; returns (dx NHWC, dbeta, dgamma)."""
+    lib = L.load()
+    B, H, W, Cc = xh.shape
+    P = B * H * W
+    t = torch.empty_like(xh)
+    L.check(lib.lic_gdn_dnorm(_ptr(g), _ptr(xh), _ptr(norm), _ptr(t), xh.numel(), int(inverse),
+                              _stream()), "lic_gdn_dnorm")
+    dxh = dbeta = dgamma = None
+    if need_dx:
+        dxh = torch.empty_like(xh)
+        _igemm(t, _pack_dense(gamma_e), dxh, B=1, Hi=1, Wi=P, Cin=Cc, Ho=1, Wo=P, Cout=Cc, kh=1, kw=1, stride=1,
+               pad=0, transposed=False, epilogue=L.EPI_IGDN_BWD if inverse else L.EPI_GDN_BWD,
+               aux=g, aux2=xh, aux3=norm)
+    if need_dbeta:
+        dbe = _colsum(t, P, Cc)
+        dbeta = torch.empty_like(beta_c)
+        L.check(lib.lic_gdn_reparam_bwd(_ptr(beta_c), _ptr(dbe), _ptr(dbeta), Cc, beta_bound,
+                                        _stream()), "lic_gdn_reparam_bwd")
+    if need_dgamma:
+        dge = torch.empty_like(gamma_e)
+        _wgrad(t, xh, dge, B=1, Hs=1, Ws=P, Cp=Cc, Hl=1, Wl=P, Cg=Cc, kh=1, kw=1, stride=1, pad=0,
+               g_is_row=False, dst_sm=Cc, dst_sn=1, dst_stap=0, sq_g=1)
+        dgamma = torch.empty_like(gamma_c)
+        L.check(lib.lic_gdn_reparam_bwd(_ptr(gamma_c), _ptr(dge), _ptr(dgamma), Cc * Cc, gamma_bound,
+                                        _stream()), "lic_gdn_reparam_bwd")
+    return dxh, dbeta, dgamma
+
+
+class _ConvGDNFn(torch.autograd.Function):
+    """conv / transposed conv followed by GDN / IGDN as ONE kernel launch (the pairs at
+    Components.py:10-15 and :39-44): the tile that produced all channels of a pixel also pools them.
+    Forward values are bitwise those of conv2d -> gdn; backward is the two ops' backward in sequence."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, beta, gamma, stride, pad, out_pad, transposed, inverse, beta_bound,
+                gamma_bound, pedestal):
+        _require_cuda(x, weight, bias, beta, gamma)
+        xh = _nhwc(x)
+        B, Hi, Wi, Cin = xh.shape
+        kh, kw = weight.shape[2], weight.shape[3]
+        Cout = weight.shape[1] if transposed else weight.shape[0]
+        Ho, Wo = conv_out_size(Hi, Wi, kh, stride, pad, transposed, out_pad)
+        wp = _pack_conv_weight(weight, transposed, for_dgrad=False)
+        beta_c, gamma_c, beta_e, gamma_e = _gdn_reparam(beta, gamma, beta_bound, gamma_bound, pedestal)
+        gT = _pack(gamma_e, 1, Cout, Cout, 0, 1, Cout)  # B operand [k=j][n=i] = gamma_e[i][j]
+        conv_out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+        norm = torch.empty_like(conv_out)
+        y = torch.empty_like(conv_out)
+        _igemm(xh, wp, y, B=B, Hi=Hi, Wi=Wi, Cin=Cin, Ho=Ho, Wo=Wo, Cout=Cout, kh=kh, kw=kw, stride=stride,
+               pad=pad, transposed=transposed, bias=bias,
+               epilogue=L.EPI_CONV_IGDN if inverse else L.EPI_CONV_GDN, out2=norm, out3=conv_out, aux=gT,
+               aux2=beta_e)
+        ctx.save_for_backward(xh, weight, conv_out, norm, gamma_e, beta_c, gamma_c)
+        ctx.cfg = (stride, pad, transposed, inverse, beta_bound, gamma_bound, bias is not None)
+        return _nchw_view(y)
+
+    @staticmethod
+    def backward(ctx, gy):
+        xh, weight, conv_out, norm, gamma_e, beta_c, gamma_c = ctx.saved_tensors
+        stride, pad, transposed, inverse, beta_bound, gamma_bound, has_bias = ctx.cfg
+        need = ctx.needs_input_grad
+        g_conv, dbeta, dgamma = _gdn_backward(conv_out, norm, gamma_e, beta_c, gamma_c, _nhwc(gy), inverse,
+                                              beta_bound, gamma_bound, True, need[3], need[4])
+        dx, dw, db = _conv_backward(xh, weight, g_conv, stride, pad, transposed, 0, need[0], need[1],
+                                    has_bias and need[2])
+        return dx, dw, db, dbeta, dgamma, None, None, None, None, None, None, None, None
+
+
+def fused_gdn_supported(cin: int, cout: int) -> bool:
+    return bool(L.load().lic_igemm_fused_gdn_supported(int(cin), int(cout)))
+
+
+def fused_gdn_preferred(x_shape, weight_shape, stride, padding, transposed, output_padding=0) -> bool:
+    """True when the one-launch conv+GDN is also expected to be faster than two launches for this
+    geometry (lic_igemm_fused_gdn_preferred: layers that run on 64-row tiles anyway)."""
+    B, Cin, Hi, Wi = x_shape
+    kh, kw = weight_shape[2], weight_shape[3]
+    Cout = weight_shape[1] if transposed else weight_shape[0]
+    Ho, Wo = conv_out_size(Hi, Wi, kh, stride, padding, transposed, output_padding)
+    d = L.IgemmDesc()
+    if not transposed and Cin < 4:  # RGB stem: columns + dense GEMM
+        d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout = 1, 1, B * Ho * Wo, _kpad(kh, kw, Cin), 1, B * Ho * Wo, Cout
+        d.kh = d.kw = d.stride = 1
+        d.pad = d.transposed = 0
+    else:
+        d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout = B, Hi, Wi, Cin, Ho, Wo, Cout
+        d.kh, d.kw, d.stride, d.pad, d.transposed = kh, kw, stride, padding, int(transposed)
+    d.in_ld, d.out_ld, d.out2_ld, d.out3_ld = d.Cin, Cout, Cout, Cout
+    return bool(L.load().lic_igemm_fused_gdn_preferred(C.byref(d)))
+
+
+def conv_gdn(x, weight, bias, beta, gamma, stride, padding, inverse, beta_bound, gamma_bound, pedestal=PEDESTAL,
+             transposed=False, output_padding=0):
+    """`gdn(conv2d(x))` / `gdn(conv_transpose2d(x))` in one launch (see _ConvGDNFn)."""
+    if not transposed and weight.shape[1] < 4:  # RGB stem: columns + dense GEMM
+        return _ImageConvGDNFn.apply(x, weight, bias, beta, gamma, stride, padding, bool(inverse),
+                                     float(beta_bound), float(gamma_bound), float(pedestal))
+    return _ConvGDNFn.apply(x, weight, bias, beta, gamma, stride, padding, output_padding, bool(transposed),
+                            bool(inverse), float(beta_bound), float(gamma_bound), float(pedestal))
 
 
 def gdn(x, beta, gamma, inverse, beta_bound, gamma_bound, pedestal=PEDESTAL, residual=None):

@@ -85,8 +85,22 @@ def run_bf16(seq: nn.Sequential, x: Tensor) -> Tensor:
     return x.float() if x.dtype != torch.float32 else x
 
 
+# conv -> GDN pairs as one launch: "auto" = where it is measured to pay (layers on 64-row tiles),
+# True = wherever the kernel supports it, False = never (tests flip it to compare the two paths)
+FUSE_CONV_GDN = "auto"
+
+
+def _conv_gdn(conv, g: "GDN", x: Tensor) -> Tensor:
+    tr = isinstance(conv, ConvTranspose2d)
+    return F_.conv_gdn(x, conv.weight, conv.bias, g.beta, g.gamma, _pair(conv.stride), _pair(conv.padding),
+                       g.inverse, g.beta_reparam.bound_value, g.gamma_reparam.bound_value,
+                       g.beta_reparam.pedestal_value, transposed=tr,
+                       output_padding=_pair(conv.output_padding) if tr else 0)
+
+
 def run_fused(seq: nn.Sequential, x: Tensor) -> Tensor:
-    """Run an nn.Sequential of our layers, folding Conv -> LeakyReLU pairs into one kernel."""
+    """Run an nn.Sequential of our layers, folding Conv -> LeakyReLU and Conv -> GDN pairs into one
+    kernel each."""
     mods = list(seq)
     i = 0
     while i < len(mods):
@@ -94,7 +108,16 @@ def run_fused(seq: nn.Sequential, x: Tensor) -> Tensor:
         nxt = mods[i + 1] if i + 1 < len(mods) else None
         fusable = isinstance(m, Conv2d) or (isinstance(m, ConvTranspose2d) and m.out_channels >= 4) or \
             (type(m).__name__ == "TransposedDeconv3x3" and m.deconv.out_channels >= 4)
-        if fusable and isinstance(nxt, LeakyReLU):
+        if FUSE_CONV_GDN and isinstance(nxt, GDN) and isinstance(m, (Conv2d, ConvTranspose2d)) and \
+                m.groups == 1 and _pair(m.dilation) == 1 and x.dim() == 4 and \
+                F_.fused_gdn_supported(m.in_channels if m.in_channels >= 4 else 4, m.out_channels) and \
+                (FUSE_CONV_GDN is True or F_.fused_gdn_preferred(
+                    tuple(x.shape), tuple(m.weight.shape), _pair(m.stride), _pair(m.padding),
+                    isinstance(m, ConvTranspose2d),
+                    _pair(m.output_padding) if isinstance(m, ConvTranspose2d) else 0)):
+            x = _conv_gdn(m, nxt, x)
+            i += 2
+        elif fusable and isinstance(nxt, LeakyReLU):
             x = m(x, leaky=True, slope=nxt.negative_slope)
             i += 2
         else:

@@ -195,6 +195,67 @@ def test_gdn(env, C, inverse, with_res):
         close(host(tres.grad), dy, 0, 0, "dres")
 
 
+# conv -> GDN as ONE launch (the pairs at Components.py:10-15, 39-44): against the oracle, and bitwise
+# against the same two ops run as separate launches
+# (sizes large enough that the stand-alone conv launch does not split K, which reorders its sums)
+@pytest.mark.parametrize("kind,ci,co,H,W,B,inverse", [("conv", 64, 64, 104, 100, 1, False),
+                                                     ("conv", 32, 192, 60, 66, 2, False),
+                                                     ("convT", 128, 128, 18, 21, 1, True),
+                                                     ("convT", 64, 192, 16, 15, 2, True),
+                                                     ("stem", 3, 128, 96, 90, 1, False)])
+def test_conv_gdn_fused(env, kind, ci, co, H, W, B, inverse):
+    nic, F_, O, dev = env
+    from neural_image_compression_amd import layers as LY
+    r = np.random.RandomState(ci * 7 + co)
+    tr = kind == "convT"
+    conv = (LY.ConvTranspose2d(ci, co, 5, stride=2, padding=2, output_padding=1) if tr
+            else LY.Conv2d(ci, co, 5, stride=2, padding=2)).to(dev)
+    g = LY.GDN(co, inverse=inverse).to(dev)
+    beta_p, gamma_p = R.make_param("g.beta", (co,), 5), R.make_param("g.gamma", (co, co), 5)
+    with torch.no_grad():
+        g.beta.copy_(torch.from_numpy(beta_p))
+        g.gamma.copy_(torch.from_numpy(gamma_p))
+    seq = torch.nn.Sequential(conv, g)
+    x = (r.rand(B, ci, H, W) if kind == "stem" else r.randn(B, ci, H, W)).astype(np.float32)
+    outs = {}
+    for fuse in (True, False):
+        LY.FUSE_CONV_GDN = fuse
+        try:
+            tx = dev_nchw(x, dev, True)
+            seq.zero_grad(set_to_none=True)
+            y = LY.run_fused(seq, tx)
+            dy = torch.from_numpy(np.random.RandomState(1).randn(*y.shape).astype(np.float32)).to(dev)
+            y.backward(dy)
+        finally:
+            LY.FUSE_CONV_GDN = "auto"
+        outs[fuse] = [y.detach(), tx.grad] + [p_.grad for p_ in seq.parameters()]
+    for a, b in zip(outs[True], outs[False]):
+        assert torch.equal(a, b), "fused conv+GDN differs from the two-launch path"
+    # oracle
+    w, b = host(conv.weight), host(conv.bias)
+    xc = O.convT2d_fwd(x, w, b, 2, 2, 1) if tr else O.conv2d_fwd(x, w, b, 2, 2)
+    beta_e, gamma_e = O.gdn_reparam(beta_p, 1e-6), O.gdn_reparam(gamma_p, 0.0)
+    y_ref, nrm = O.gdn_fwd(xc, beta_e, gamma_e, inverse)
+    close_norm(host(outs[True][0]), y_ref, 1e-4, "y")
+    dx_c, dbe, dge = O.gdn_bwd(xc, nrm, gamma_e, host(dy), inverse)
+    dx, dw, db = (O.convT2d_bwd(x, w, dx_c, 2, 2, 1) if tr else O.conv2d_bwd(x, w, dx_c, 2, 2))
+    close_norm(host(outs[True][1]), dx, 3e-4, "dx")
+    close_norm(host(conv.weight.grad), dw, 3e-4, "dw")
+    close_norm(host(conv.bias.grad), db, 3e-4, "db")
+    close_norm(host(g.gamma.grad), O.gdn_reparam_bwd(gamma_p, dge, 0.0), 3e-4, "dgamma")
+
+
+def test_conv_gdn_fused_rejects_unsupported(env):
+    nic, F_, O, dev = env
+    assert F_.fused_gdn_supported(64, 192) and F_.fused_gdn_supported(76, 128)
+    assert not F_.fused_gdn_supported(64, 96) and not F_.fused_gdn_supported(64, 320)
+    # "preferred" = the layers that run on 64-row tiles anyway: the RGB stem and small grids
+    assert F_.fused_gdn_preferred((32, 3, 256, 256), (192, 3, 5, 5), 2, 2, False)
+    assert F_.fused_gdn_preferred((32, 192, 64, 64), (192, 192, 5, 5), 2, 2, False)
+    assert not F_.fused_gdn_preferred((32, 192, 128, 128), (192, 192, 5, 5), 2, 2, False)
+    assert not F_.fused_gdn_preferred((32, 192, 64, 64), (192, 192, 5, 5), 2, 2, True, 1)
+
+
 # ---------------------------------------------------------------------------------------------
 # entropy models vs reference-pinned goldens and the oracle
 # ---------------------------------------------------------------------------------------------
