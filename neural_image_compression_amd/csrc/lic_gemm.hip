@@ -74,19 +74,28 @@ struct IgemmParams {
 constexpr int IG_BK = 16;
 constexpr int IG_LDA = IG_BK + 4;
 
+// 16 zero bytes: the source of LDS-DMA lanes that fall on padding / past the last pixel
+__device__ __attribute__((aligned(16))) float g_lic_zero16[4];
+typedef const __attribute__((address_space(1))) void* lic_gptr_t;
+typedef __attribute__((address_space(3))) void* lic_lptr_t;
+
 // FULLN: every wave of every workgroup has all its TN column tiles live (Npad % (64*TN) == 0), so
 // the MFMA block is branch-free.  (With the scalar branches of the ragged variant hipcc shuffles
 // accumulators through v_accvgpr_read/mov at the joins: ~2 extra AGPR moves per MFMA.)
 // FUSE (BM = 64, one N tile covering all channels): the GDN / IGDN that follows the convolution
 // runs in this kernel's epilogue -- see the block after the K loop.
-template <int BM, int TN, bool VEC, bool FULLN, bool FUSE = false>
+// GLDS (VEC, FULLN, no prologue): both operands reach LDS by LDS-DMA (`global_load_lds_dwordx4`):
+// no staging registers, no ds_write pass and no B registers held across a chunk; see the loop.
+template <int BM, int TN, bool VEC, bool FULLN, bool FUSE = false, bool GLDS = false>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   constexpr int BN = 64 * TN;
   constexpr int WM = BM / 2, WN = BN / 2;  // 2x2 waves
   constexpr int TM = WM / 32;              // MFMA tiles per wave in M
   constexpr int APASS = BM / 64;           // float4 A loads per thread per chunk
   // A double buffer; after the K loop the same memory stages 32x32 output tiles (one per wave)
-  constexpr int SA_MAIN = (2 * BM * IG_LDA > 4 * 1024) ? 2 * BM * IG_LDA : 4 * 1024;
+  constexpr int GL_BUF = (BM + BN) * IG_BK;  // GLDS: floats of one (A tile, B panel) buffer
+  constexpr int SA_MAIN = GLDS ? 2 * GL_BUF : ((2 * BM * IG_LDA > 4 * 1024) ? 2 * BM * IG_LDA : 4 * 1024);
+  static_assert(!GLDS || (VEC && FULLN && 2 * GL_BUF >= 4 * 1024), "LDS-DMA variant: float4 gathers, full N");
   // fused GDN epilogue: x tile [64][BN+4] + one 32x32 patch per wave
   constexpr int SA_FLOATS = (FUSE && 64 * (BN + 4) + 4096 > SA_MAIN) ? 64 * (BN + 4) + 4096 : SA_MAIN;
   static_assert(!FUSE || (VEC && FULLN), "fused GDN epilogue: float4 gathers, full N");
@@ -276,6 +285,87 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
       ++l_tap;
     }
   };
+  if constexpr (GLDS) {
+    // LDS image of one buffer: A tile [BM][16] packed (64-byte rows; thread t of pass j owns row
+    // t/4 + 64j, 16-byte slot t%4, i.e. byte 16*t + 4096*j -- the wave-linear order the DMA writes),
+    // then the B panel of this N tile exactly as packed in memory ([32-col tile][q][lane][4]).
+    // Packed 64-byte rows would put rows r, r+4, r+8, r+12 of a ds_read_b128 lane group on the same
+    // banks, so slot s of row r holds K-quad s ^ ((r >> 2) & 3): the swizzle is applied to the
+    // per-lane SOURCE address here and to the fragment reads below.
+    const int gq = ((tid & 3) ^ ((tid >> 4) & 3)) * 4;  // this thread's logical channel offset in a chunk
+    auto issue = [&](int tapi, int cb, int buf) {
+      const bool past = tapi > last_tap;
+      const int tap = p.taps[phase][past ? last_tap : tapi];
+      const int cbb = past ? last_cb : cb;
+      const int r = tap / p.kw, s = tap - r * p.kw;
+      const int ci = cbb * IG_BK + gq;
+      float* dstA = smem + buf * GL_BUF;
+#pragma unroll
+      for (int j = 0; j < APASS; ++j) {
+        const int nh = a_hy[j] + sgn * r, nw = a_wx[j] + sgn * s;
+        const int ih = nh >> sh, iw = nw >> sh;
+        const bool ok = a_ok[j] && nh >= 0 && nw >= 0 && ih < p.Hi && iw < p.Wi && ci < p.Cin;
+        // selects, not a branch: the DMA must stay in the MFMAs' basic block
+        const int okm = -(int)ok;
+        const long off = (long)((a_base[j] + ih * p.Wi + iw) & okm) * p.in_ld + (ci & okm);
+        const float* src = (ok ? p.in : g_lic_zero16) + off;
+        __builtin_amdgcn_global_load_lds((lic_gptr_t)src, (lic_lptr_t)(dstA + j * 1024 + wave * 256), 16, 0, 0);
+      }
+      const float* wsrc = p.w + ((long)tap * p.cpt + cbb) * p.Npad * IG_BK + (long)n0 * IG_BK + tid * 4;
+      float* dstB = dstA + BM * IG_BK;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        __builtin_amdgcn_global_load_lds((lic_gptr_t)(wsrc + j * 1024), (lic_lptr_t)(dstB + j * 1024 + wave * 256),
+                                         16, 0, 0);
+    };
+    auto compute_g = [&](int buf) {
+      const float* bA = smem + buf * GL_BUF;
+      const float* bB = bA + BM * IG_BK + (wn0 >> 5) * 512 + lane * 4;
+      f32x4 af[TM][2], bf[TN][2];
+#pragma unroll
+      for (int a = 0; a < TM; ++a) {
+        const int row = wm0 + a * 32 + li;
+        const int sw = (row >> 2) & 3;
+        af[a][0] = *reinterpret_cast<const f32x4*>(bA + row * IG_BK + (((lh * 2) ^ sw) * 4));
+        af[a][1] = *reinterpret_cast<const f32x4*>(bA + row * IG_BK + (((lh * 2 + 1) ^ sw) * 4));
+      }
+#pragma unroll
+      for (int b = 0; b < TN; ++b) {
+        bf[b][0] = *reinterpret_cast<const f32x4*>(bB + b * 512);
+        bf[b][1] = *reinterpret_cast<const f32x4*>(bB + b * 512 + 256);
+      }
+#pragma unroll
+      for (int t = 0; t < 8; ++t)
+#pragma unroll
+        for (int b = 0; b < TN; ++b)
+#pragma unroll
+          for (int a = 0; a < TM; ++a)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][t >> 2][t & 3], bf[b][t >> 2][t & 3],
+                                                              acc[a][b], 0, 0, 0);
+    };
+    if (nchunks > 0) {
+      // Two buffers; per chunk: __syncthreads (vmcnt(0): my DMA of chunk c landed; barrier: everyone's
+      // did and everyone is done reading chunk c-1) -> issue the DMA of chunk c+1 -> MFMAs of chunk c.
+      issue(l_tap, l_cb, 0);
+      advance();
+      int c = 0;
+      for (; c + 1 < nchunks; c += 2) {  // branch-free body, single exit; past-the-end DMAs are duplicates
+        __syncthreads();
+        issue(l_tap, l_cb, 1);
+        advance();
+        compute_g(0);
+        __builtin_amdgcn_sched_barrier(0);  // keep the vmcnt(0)+barrier BEHIND this chunk's MFMAs
+        __syncthreads();
+        issue(l_tap, l_cb, 0);
+        advance();
+        compute_g(1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+      if (c < nchunks) compute_g(0);
+      __syncthreads();  // the epilogue reuses the buffers
+    }
+  } else {
   f32x4 rb0[TN][2], rb1[TN][2];
   if (nchunks > 0) {
     load_a(l_tap, l_cb);
@@ -323,6 +413,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
       __syncthreads();
     }
   }
+  }  // !GLDS
 
 
   // ---- fused GDN / IGDN (LIC_EPI_CONV_GDN / LIC_EPI_CONV_IGDN) ----------------------------------
@@ -872,9 +963,12 @@ LIC_EXPORT int lic_igemm(const lic_igemm_desc* d, lic_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)nwg), block(256);
   const bool full = (p.Npad % (64 * TN)) == 0;
+  const bool glds = full && p.prologue == 0 && getenv("LIC_IGEMM_NO_GLDS") == nullptr;
 #define LIC_IGEMM_LAUNCH(bm, tn)                                                        \
   do {                                                                                  \
-    if (full)                                                                           \
+    if (glds)                                                                           \
+      hipLaunchKernelGGL((igemm_kernel<bm, tn, true, true, false, true>), grid, block, 0, s, p); \
+    else if (full)                                                                      \
       hipLaunchKernelGGL((igemm_kernel<bm, tn, true, true>), grid, block, 0, s, p);     \
     else                                                                                \
       hipLaunchKernelGGL((igemm_kernel<bm, tn, true, false>), grid, block, 0, s, p);    \
@@ -1115,9 +1209,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     }
 }
 
-// 16 zero bytes: the source of LDS-DMA lanes that fall on padding / past the last pixel
-__device__ __attribute__((aligned(16))) float g_lic_zero16[4];
-
 // LDS-DMA variant of wgrad_kernel for full tiles without a squaring prologue: both operands go
 // global -> LDS with `global_load_lds_dwordx4` (no staging registers, no ds_write pass, no vmcnt
 // wait in front of an LDS store).  The LDS image is [64-channel sub-tile][16 px][64 ch]: thread t
@@ -1158,8 +1249,8 @@ __global__ __launch_bounds__(256) void wgrad_glds_kernel(const WgradParams p) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.0f;
 
-  typedef const __attribute__((address_space(1))) void* gptr_t;
-  typedef __attribute__((address_space(3))) void* lptr_t;
+  typedef lic_gptr_t gptr_t;
+  typedef lic_lptr_t lptr_t;
   const int kr = tid >> 4, c16 = (tid & 15) * 4;
   // chunk indices past the end are clamped to the last one (harmless duplicate DMA into the idle buffer)
   auto issue = [&](int c, int buf) {
