@@ -110,6 +110,8 @@ int lic_igemm_fused_gdn_preferred(const lic_igemm_desc* d);
 size_t lic_igemm_workspace_bytes(const lic_igemm_desc* d);
 
 int lic_igemm(const lic_igemm_desc* d, lic_stream_t stream);
+/* name of the kernel variant lic_igemm launches for `d`, as rocprofv3 prints it (profiling aid) */
+int lic_igemm_kernel_name(const lic_igemm_desc* d, char* buf, size_t n);
 /* Weight packing for lic_igemm.  Logical element (tap, k, n) is read from
  * src[tap*s_tap + k*s_k + n*s_n]; dst holds lic_packed_weight_floats(taps, K, N) floats
  * (zero padded).  Any [Cout,Cin,kh,kw] / [Cin,Cout,kh,kw] weight, its transpose for the data
@@ -148,6 +150,12 @@ size_t lic_wgrad_workspace_bytes(const lic_wgrad_desc* d);
 int lic_wgrad(const lic_wgrad_desc* d, void* workspace, size_t workspace_bytes, lic_stream_t stream);
 /* kernel variant wgrad_kernel<TM,TN,...> and split-K factor lic_wgrad will use (profiling aid) */
 int lic_wgrad_plan(const lic_wgrad_desc* d, int32_t* TM, int32_t* TN, int32_t* splitk);
+/* lic_wgrad in two steps, so a profiler can time the MFMA kernel apart from the slab reduction:
+ * stage 1 = partial sums only, stage 2 = reduction only, 0 = both (== lic_wgrad) */
+int lic_wgrad_stage(const lic_wgrad_desc* d, void* workspace, size_t workspace_bytes, int32_t stage,
+                    lic_stream_t stream);
+/* name of the MFMA kernel lic_wgrad launches for `d`, as rocprofv3 prints it */
+int lic_wgrad_kernel_name(const lic_wgrad_desc* d, char* buf, size_t n);
 
 /* column sums over pixels: out[c] = scale * sum_p in[p*ld + c]  (bias gradients, GDN dbeta) */
 size_t lic_colsum_workspace_bytes(int64_t P, int32_t C);

@@ -45,6 +45,9 @@ class WgradDesc(C.Structure):
 SIGNATURES = {
     "lic_igemm": (C.c_int, [C.POINTER(IgemmDesc), _vp]),
     "lic_igemm_workspace_bytes": (_sz, [C.POINTER(IgemmDesc)]),
+    "lic_igemm_kernel_name": (C.c_int, [C.POINTER(IgemmDesc), C.c_char_p, _sz]),
+    "lic_wgrad_stage": (C.c_int, [C.POINTER(WgradDesc), _vp, _sz, _i32, _vp]),
+    "lic_wgrad_kernel_name": (C.c_int, [C.POINTER(WgradDesc), C.c_char_p, _sz]),
     "lic_igemm_plan": (C.c_int, [C.POINTER(IgemmDesc), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i64)]),
     "lic_packed_weight_floats": (_i64, [_i32, _i32, _i32]),
     "lic_pack_weight": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _vp]),

@@ -5,6 +5,7 @@
 // through LDS, the next chunk's global loads are issued before the current chunk's MFMAs, and
 // 3-4 workgroups per CU cover each other's load/store phases.
 #include "lic_common.h"
+#include <stdio.h>
 #include <stdlib.h>
 
 thread_local int g_lic_last_hip_error = 0;
@@ -328,6 +329,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         const int sw = (row >> 2) & 3;
         af[a][0] = *reinterpret_cast<const f32x4*>(bA + row * IG_BK + (((lh * 2) ^ sw) * 4));
         af[a][1] = *reinterpret_cast<const f32x4*>(bA + row * IG_BK + (((lh * 2 + 1) ^ sw) * 4));
+        af[a][0] = sq ? af[a][0] * af[a][0] : af[a][0];  // prologue 1 (GDN pool): square at the read
+        af[a][1] = sq ? af[a][1] * af[a][1] : af[a][1];
       }
 #pragma unroll
       for (int b = 0; b < TN; ++b) {
@@ -952,6 +955,26 @@ LIC_EXPORT int lic_igemm_plan(const lic_igemm_desc* d, int32_t* BM, int32_t* BN,
   return LIC_OK;
 }
 
+// name of the kernel variant lic_igemm launches for `d`, as rocprofv3 prints it (profiling aid)
+LIC_EXPORT int lic_igemm_kernel_name(const lic_igemm_desc* d, char* buf, size_t n) {
+  IgemmParams p;
+  int BM = 0, TN = 0;
+  long nwg = 0;
+  int64_t macs = 0;
+  const int rc = igemm_prepare(d, p, BM, TN, nwg, macs);
+  if (rc < 0) return rc;
+  if (!buf || n == 0) return LIC_ERR_INVALID;
+  const bool full = (p.Npad % (64 * TN)) == 0;
+  const bool fuse = p.epilogue == LIC_EPI_CONV_GDN || p.epilogue == LIC_EPI_CONV_IGDN;
+  const bool glds = full && p.vec && getenv("LIC_IGEMM_NO_GLDS") == nullptr;
+  if (!p.vec)
+    snprintf(buf, n, "igemm_kernel<64, 1, false, false, false, false>");
+  else
+    snprintf(buf, n, "igemm_kernel<%d, %d, true, %s, %s, %s>", BM, TN, full ? "true" : "false",
+             fuse ? "true" : "false", (glds || fuse) ? "true" : "false");
+  return LIC_OK;
+}
+
 LIC_EXPORT int lic_igemm(const lic_igemm_desc* d, lic_stream_t stream) {
   IgemmParams p;
   int BM = 0, TN = 0;
@@ -963,7 +986,7 @@ LIC_EXPORT int lic_igemm(const lic_igemm_desc* d, lic_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)nwg), block(256);
   const bool full = (p.Npad % (64 * TN)) == 0;
-  const bool glds = full && p.prologue == 0 && getenv("LIC_IGEMM_NO_GLDS") == nullptr;
+  const bool glds = full && getenv("LIC_IGEMM_NO_GLDS") == nullptr;
 #define LIC_IGEMM_LAUNCH(bm, tn)                                                        \
   do {                                                                                  \
     if (glds)                                                                           \
@@ -975,11 +998,11 @@ LIC_EXPORT int lic_igemm(const lic_igemm_desc* d, lic_stream_t stream) {
   } while (0)
   if (p.epilogue == LIC_EPI_CONV_GDN || p.epilogue == LIC_EPI_CONV_IGDN) {
     if (TN == 3)
-      hipLaunchKernelGGL((igemm_kernel<64, 3, true, true, true>), grid, block, 0, s, p);
+      hipLaunchKernelGGL((igemm_kernel<64, 3, true, true, true, true>), grid, block, 0, s, p);
     else if (TN == 2)
-      hipLaunchKernelGGL((igemm_kernel<64, 2, true, true, true>), grid, block, 0, s, p);
+      hipLaunchKernelGGL((igemm_kernel<64, 2, true, true, true, true>), grid, block, 0, s, p);
     else
-      hipLaunchKernelGGL((igemm_kernel<64, 1, true, true, true>), grid, block, 0, s, p);
+      hipLaunchKernelGGL((igemm_kernel<64, 1, true, true, true, true>), grid, block, 0, s, p);
   } else if (!p.vec)  // odd channel counts / unaligned views: scalar-load variant, one tile shape
     hipLaunchKernelGGL((igemm_kernel<64, 1, false, false>), grid, block, 0, s, p);
   else if (BM == 128 && TN == 3)
@@ -1209,7 +1232,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
     }
 }
 
-// LDS-DMA variant of wgrad_kernel for full tiles without a squaring prologue: both operands go
+// LDS-DMA variant of wgrad_kernel for full tiles: both operands go
 // global -> LDS with `global_load_lds_dwordx4` (no staging registers, no ds_write pass, no vmcnt
 // wait in front of an LDS store).  The LDS image is [64-channel sub-tile][16 px][64 ch]: thread t
 // owns pixel t/16, channels (t%16)*4.. of every sub-tile, i.e. byte t*16 of it -- exactly the
@@ -1278,19 +1301,26 @@ __global__ __launch_bounds__(256) void wgrad_glds_kernel(const WgradParams p) {
       __builtin_amdgcn_global_load_lds((gptr_t)(colp ? colp + 64 * j : g_lic_zero16),
                                        (lptr_t)&smem[buf][TM + j][wave * 256], 16, 0, 0);
   };
+  const bool sqa = p.row.sq != 0, sqb = p.col.sq != 0;  // GDN d-gamma: squared operand, applied at the read
   auto compute = [&](int buf) {
     float af[TM][8], bf[TN][8];
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
       const int ch = wm0 + a * 32;
 #pragma unroll
-      for (int t = 0; t < 8; ++t) af[a][t] = smem[buf][ch >> 6][(lh * 8 + t) * 64 + (ch & 63) + li];
+      for (int t = 0; t < 8; ++t) {
+        const float v = smem[buf][ch >> 6][(lh * 8 + t) * 64 + (ch & 63) + li];
+        af[a][t] = sqa ? v * v : v;
+      }
     }
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
       const int ch = wn0 + b * 32;
 #pragma unroll
-      for (int t = 0; t < 8; ++t) bf[b][t] = smem[buf][TM + (ch >> 6)][(lh * 8 + t) * 64 + (ch & 63) + li];
+      for (int t = 0; t < 8; ++t) {
+        const float v = smem[buf][TM + (ch >> 6)][(lh * 8 + t) * 64 + (ch & 63) + li];
+        bf[b][t] = sqb ? v * v : v;
+      }
     }
 #pragma unroll
     for (int t = 0; t < 8; ++t)
@@ -1384,8 +1414,35 @@ LIC_EXPORT size_t lic_wgrad_workspace_bytes(const lic_wgrad_desc* d) {
   return (size_t)pl.splitk * pl.ntaps * pl.Cm * pl.Cn * sizeof(float);
 }
 
+static int wgrad_run(const lic_wgrad_desc* d, void* workspace, size_t workspace_bytes, int stage,
+                     lic_stream_t stream);
 LIC_EXPORT int lic_wgrad(const lic_wgrad_desc* d, void* workspace, size_t workspace_bytes,
                          lic_stream_t stream) {
+  return wgrad_run(d, workspace, workspace_bytes, 0, stream);
+}
+// stage 1: the partial-sum kernel only; stage 2: the slab reduction only (0 = both, as lic_wgrad).
+// Lets a profiler time the MFMA kernel apart from the reduction.
+LIC_EXPORT int lic_wgrad_stage(const lic_wgrad_desc* d, void* workspace, size_t workspace_bytes,
+                               int32_t stage, lic_stream_t stream) {
+  if (stage < 0 || stage > 2) return LIC_ERR_INVALID;
+  return wgrad_run(d, workspace, workspace_bytes, stage, stream);
+}
+LIC_EXPORT int lic_wgrad_kernel_name(const lic_wgrad_desc* d, char* buf, size_t n) {
+  WgPlan pl;
+  const int rc = wg_plan(d, &pl);
+  if (rc != LIC_OK) return rc;
+  if (!buf || n == 0) return LIC_ERR_INVALID;
+  const bool full = (pl.Cm % (64 * pl.TM) == 0) && (pl.Cn % (64 * pl.TN) == 0);
+  if (!pl.vec)
+    snprintf(buf, n, "wgrad_kernel<1, 1, false, false>");
+  else if (full && getenv("LIC_WGRAD_NO_GLDS") == nullptr)
+    snprintf(buf, n, "wgrad_glds_kernel<%d, %d>", pl.TM, pl.TN);
+  else
+    snprintf(buf, n, "wgrad_kernel<%d, %d, true, %s>", pl.TM, pl.TN, full ? "true" : "false");
+  return LIC_OK;
+}
+static int wgrad_run(const lic_wgrad_desc* d, void* workspace, size_t workspace_bytes, int stage,
+                     lic_stream_t stream) {
   WgPlan pl;
   int rc = wg_plan(d, &pl);
   if (rc != LIC_OK) return rc;
@@ -1429,7 +1486,8 @@ LIC_EXPORT int lic_wgrad(const lic_wgrad_desc* d, void* workspace, size_t worksp
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(pl.MTt * pl.NTt * pl.ntaps * pl.splitk), block(256);
   const bool full = (pl.Cm % (64 * pl.TM) == 0) && (pl.Cn % (64 * pl.TN) == 0);
-  const bool glds = full && !d->sq_p && !d->sq_g && getenv("LIC_WGRAD_NO_GLDS") == nullptr;
+  const bool glds = full && getenv("LIC_WGRAD_NO_GLDS") == nullptr;
+  if (stage != 2) {
 #define LIC_WGRAD_LAUNCH(tm, tn)                                                      \
   do {                                                                                \
     if (glds)                                                                         \
@@ -1454,6 +1512,8 @@ LIC_EXPORT int lic_wgrad(const lic_wgrad_desc* d, void* workspace, size_t worksp
 #undef LIC_WGRAD_LAUNCH
   rc = lic_check_launch();
   if (rc != LIC_OK) return rc;
+  }
+  if (stage == 1) return LIC_OK;
   const long total = (long)pl.ntaps * pl.Cm * pl.Cn;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, s,
                      (const float*)workspace, d->dst, pl.splitk, pl.ntaps, pl.Cm, pl.Cn, (long)d->dst_sm,

@@ -119,21 +119,18 @@ def _igemm(inp, w_packed, out, *, B, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, 
         return
     bm, bn, macs = C.c_int32(0), C.c_int32(0), C.c_int64(0)
     lib.lic_igemm_plan(C.byref(d), C.byref(bm), C.byref(bn), C.byref(macs))
+    nm = C.create_string_buffer(96)
+    lib.lic_igemm_kernel_name(C.byref(d), nm, 96)  # as rocprofv3 prints it
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     L.check(lib.lic_igemm(C.byref(d), _stream()), "lic_igemm")
     e1.record()
     act_bytes = 4 * (B * Hi * Wi * Cin + B * Ho * Wo * Cout)
-    vec = Cin % 4 == 0 and d.in_ld % 4 == 0
-    tn = bn.value // 64
-    full = vec and ((Cout + 31) // 32 * 32) % (64 * tn) == 0
-    name = f"igemm_kernel<{bm.value}, {tn}, {str(vec).lower()}, {str(full).lower()}>"  # as rocprofv3 prints it
     flops = 2 * macs.value
     if fused:  # conv + the channel pool of the GDN that follows it
-        name = f"igemm_kernel<{bm.value}, {tn}, true, true, true>"
         flops += 2 * B * Ho * Wo * Cout * Cout
         act_bytes += 4 * 2 * B * Ho * Wo * Cout
-    PROFILE.append((name, flops, act_bytes, e0, e1))
+    PROFILE.append((nm.value.decode(), flops, act_bytes, e0, e1))
 
 
 def _wgrad(p, g, dst, *, B, Hs, Ws, Cp, Hl, Wl, Cg, kh, kw, stride, pad, g_is_row, dst_sm, dst_sn,
@@ -151,15 +148,15 @@ def _wgrad(p, g, dst, *, B, Hs, Ws, Cp, Hl, Wl, Cg, kh, kw, stride, pad, g_is_ro
     if PROFILE is None:
         L.check(lib.lic_wgrad(C.byref(d), _ptr(ws), nbytes, _stream()), "lic_wgrad")
         return
+    nm = C.create_string_buffer(96)
+    lib.lic_wgrad_kernel_name(C.byref(d), nm, 96)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    L.check(lib.lic_wgrad(C.byref(d), _ptr(ws), nbytes, _stream()), "lic_wgrad")
+    e0.record()  # the MFMA kernel alone; the slab reduction runs after the second event
+    L.check(lib.lic_wgrad_stage(C.byref(d), _ptr(ws), nbytes, 1, _stream()), "lic_wgrad_stage")
     e1.record()
+    L.check(lib.lic_wgrad_stage(C.byref(d), _ptr(ws), nbytes, 2, _stream()), "lic_wgrad_stage")
     flops = 2 * B * Hs * Ws * kh * kw * Cp * Cg
-    tm, tn, sk = C.c_int32(0), C.c_int32(0), C.c_int32(0)
-    lib.lic_wgrad_plan(C.byref(d), C.byref(tm), C.byref(tn), C.byref(sk))
-    PROFILE.append((f"wgrad_kernel<{tm.value}, {tn.value}>+reduce", flops,
-                    4 * (B * Hs * Ws * Cp + B * Hl * Wl * Cg), e0, e1))
+    PROFILE.append((nm.value.decode(), flops, 4 * (B * Hs * Ws * Cp + B * Hl * Wl * Cg), e0, e1))
 
 
 def _colsum(t2d: torch.Tensor, P: int, Cc: int, scale: float = 1.0) -> torch.Tensor:
