@@ -132,6 +132,8 @@ def main():
     ap.add_argument("--config", default="2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-events", action="store_true")
+    ap.add_argument("--no-analysis-fwd", action="store_true",
+                    help="skip the separate analysis+hyperprior forward timing (keeps a rocprofv3 trace to the K steps)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -233,7 +235,9 @@ def main():
             # runs of this same command, gfx950 x2 read correction applied; see the file's "_how")
             traffic = None
             try:
-                pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["kernels"]
+                import glob
+                newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
+                pmc = json.load(open(newest))["kernels"]
                 for kname, v in pmc.items():
                     if dom in kname and (H, W, B, M, K) == (256, 256, 32, 192, 1):
                         traffic = v["traffic_bytes_per_launch"]
@@ -251,7 +255,7 @@ def main():
                                    "tflops": round(v[2] / max(v[1], 1e-12) / 1e12, 2)} for k, v in agg.items()}
             mfma_s = sum(v[1] for v in agg.values())
             line["mfma_kernel_share_of_step"] = round(mfma_s / el, 4)
-        if world == 1:
+        if world == 1 and not args.no_analysis_fwd:
             line["analysis_hyperprior_fwd"] = analysis_hyperprior_fwd(model, x, F_, bf16)
         if world == 1 and not args.no_cpu_baseline:
             try:
