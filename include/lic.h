@@ -263,6 +263,22 @@ int lic_gdn_dnorm_bf16(const void* g, const void* x, const void* norm, void* t, 
                        lic_stream_t stream);
 
 /* ---- misc ---------------------------------------------------------------------------------- */
+/* ------------------------------------------------------------------------------------------
+ * SURVEY 8(f).1 -- evaluation metric on the device.
+ * Multi-scale SSIM exactly as the reference's evaluator calls it (Evaluator.py:7,38,45:
+ * `ms_ssim(recon, orig, data_range=1.0, size_average=True)` of the third-party pytorch-msssim==0.2.1,
+ * requirements.txt:5 -- absent offline, PARITY UNPINNED; follows the package's published algorithm:
+ * 11-tap sigma-1.5 Gaussian window, valid filtering, K=(0.01,0.03), 5 scales, 2x2 average pooling with
+ * zero padding of odd sides, default weights).  x, y: element (b,c,h,w) at b*sb + c*sc + h*sh + w*sw
+ * (any NCHW / channels_last view).  out[B*C] = per-image per-channel MS-SSIM (the package's value is
+ * its mean); level_out[5][B*C][2] = per-scale (mean ssim, mean cs).  min(H, W) must exceed 160 (the
+ * package's assertion) -> LIC_ERR_UNSUPPORTED otherwise.
+ * ------------------------------------------------------------------------------------------ */
+size_t lic_msssim_workspace_bytes(int32_t B, int32_t C, int32_t H, int32_t W);
+int lic_msssim(const float* x, const float* y, int32_t B, int32_t C, int32_t H, int32_t W, int64_t sb,
+               int64_t sc, int64_t sh, int64_t sw, float data_range, float* out, float* level_out,
+               void* workspace, size_t workspace_bytes, lic_stream_t stream);
+
 int lic_version(void);        /* LIC_ABI_VERSION */
 int lic_last_hip_error(void); /* hipError_t of the most recent failed launch on this thread */
 const char* lic_arch(void);   /* "gfx950" */

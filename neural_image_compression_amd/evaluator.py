@@ -2,8 +2,9 @@
 235-242): per-batch bpp_total / bpp_y / bpp_z from rd_loss, MSE(255), PSNR(RGB) on
 x_hat.clamp(0,1), luma PSNR with BT.601 weights, and the result-file format.
 
-Differences, stated: MS-SSIM needs the third-party `pytorch_msssim` (absent offline; SURVEY.md
-8(f)) and is reported only when that package is importable.  The reference's aggregation reports
+Differences, stated: MS-SSIM (third-party `pytorch_msssim` in the reference, absent offline) is
+computed on the device by `functional.ms_ssim` / `lic_msssim`, which follows that package's
+published 0.2.1 algorithm (parity unpinned).  The reference's aggregation reports
 `BPP` = mean(bpp_y) (Evaluator.py:81 uses bpp_y_values); this class reproduces that under 'BPP'
 for drop-in compatibility and adds the intended value as 'BPP(total)'.
 """
@@ -24,11 +25,8 @@ class CompressionEvaluator:
         self.lambda_val = lambda_val
         os.makedirs(save_dir, exist_ok=True)
         self.save_dir = save_dir
-        try:
-            from pytorch_msssim import ms_ssim  # noqa: WPS433
-            self._ms_ssim = ms_ssim
-        except Exception:
-            self._ms_ssim = None
+        from .functional import ms_ssim
+        self._ms_ssim = ms_ssim
 
     @staticmethod
     def rgb_to_luma(x):
@@ -42,11 +40,9 @@ class CompressionEvaluator:
         Y_orig = self.rgb_to_luma(orig).unsqueeze(1)
         Y_recon = self.rgb_to_luma(recon).unsqueeze(1)
         mse_y = torch.mean((Y_orig - Y_recon) ** 2).item()
-        if self._ms_ssim is not None:
-            out["MS-SSIM(RGB)"] = self._ms_ssim(recon, orig, data_range=1.0, size_average=True).item()
+        out["MS-SSIM(RGB)"] = self._ms_ssim(recon, orig, data_range=1.0, size_average=True).item()
         out["PSNR(Y)"] = 10 * math.log10(1.0 / mse_y) if mse_y > 0 else float('inf')
-        if self._ms_ssim is not None:
-            out["MS-SSIM(Y)"] = self._ms_ssim(Y_recon, Y_orig, data_range=1.0, size_average=True).item()
+        out["MS-SSIM(Y)"] = self._ms_ssim(Y_recon, Y_orig, data_range=1.0, size_average=True).item()
         return out
 
     def evaluate(self, rd_loss_fn):

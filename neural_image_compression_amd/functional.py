@@ -837,3 +837,34 @@ def mask_weight_(weight: torch.Tensor, mask: torch.Tensor):
     _require_cuda(weight, mask)
     L.check(L.load().lic_mul_inplace(_ptr(weight.data), _ptr(mask), weight.numel(), _stream()),
             "lic_mul_inplace")
+
+
+# ------------------------------------------------------------------------------------------
+# evaluation metric: MS-SSIM as Evaluator.py:38,45 calls pytorch-msssim 0.2.1
+# ------------------------------------------------------------------------------------------
+def ms_ssim(X: torch.Tensor, Y: torch.Tensor, data_range: float = 255.0, size_average: bool = True):
+    """`pytorch_msssim.ms_ssim(X, Y, data_range, size_average)` (default window / weights / K) on the
+    device.  X, Y: [B,C,H,W] fp32 CUDA tensors (any strides), min(H,W) > 160.  Returns the mean over
+    batch and channels, or the per-image channel mean when `size_average=False`.  No gradient."""
+    _require_cuda(X, Y)
+    if X.shape != Y.shape or X.dim() != 4:
+        raise ValueError(f"Input images should have the same 4-d shape, got {tuple(X.shape)} and {tuple(Y.shape)}")
+    B, Cc, H, W = X.shape
+    if min(H, W) <= 160:
+        raise ValueError("Image size should be larger than 160 due to the 4 downsamplings in ms-ssim")
+    Xd = X.detach().float()
+    Yd = Y.detach().float()
+    if Yd.stride() != Xd.stride():
+        Yd = Yd.contiguous(memory_format=torch.channels_last if Xd.is_contiguous(memory_format=torch.channels_last)
+                           and not Xd.is_contiguous() else torch.contiguous_format)
+        if Yd.stride() != Xd.stride():
+            Xd, Yd = Xd.contiguous(), Yd.contiguous()
+    lib = L.load()
+    nbytes = lib.lic_msssim_workspace_bytes(B, Cc, H, W)
+    ws = torch.empty((nbytes + 7) // 8, device=X.device, dtype=torch.float64)
+    out = torch.empty((B, Cc), device=X.device, dtype=torch.float32)
+    levels = torch.empty((5, B * Cc, 2), device=X.device, dtype=torch.float32)
+    sb, sc, sh, sw = Xd.stride()
+    L.check(lib.lic_msssim(_ptr(Xd), _ptr(Yd), B, Cc, H, W, sb, sc, sh, sw, float(data_range), _ptr(out),
+                           _ptr(levels), _ptr(ws), nbytes, _stream()), "lic_msssim")
+    return out.mean() if size_average else out.mean(1)

@@ -220,3 +220,56 @@ def step(state: Dict[str, "object"], x, M, K, kind="5x5", noise=None, lambda_rd=
     grads = {k: v.grad.numpy() for k, v in P.items() if v.requires_grad and v.grad is not None}
     loss = {k: float(v.detach()) for k, v in res.items() if v.dim() == 0}
     return {k: (v.detach().numpy() if torch.is_tensor(v) else v) for k, v in out.items()}, loss, grads
+
+
+# ----------------------------------------------------------------------------------------------
+# MS-SSIM.  The reference calls `pytorch_msssim.ms_ssim(recon, orig, data_range=1.0,
+# size_average=True)` (Evaluator.py:7,38,45; requirements.txt:5 pins pytorch-msssim==0.2.1, which is
+# not installable offline => PARITY UNPINNED).  Restated from the package's published algorithm.
+# ----------------------------------------------------------------------------------------------
+def _msssim_window(size=11, sigma=1.5):
+    coords = torch.arange(size, dtype=torch.float32) - size // 2
+    g = torch.exp(-(coords ** 2) / (2 * sigma ** 2))
+    return g / g.sum()
+
+
+def _msssim_filter(x, g):
+    """separable VALID Gaussian filtering per channel, H first then W (as the package loops)"""
+    C = x.shape[1]
+    k = g.numel()
+    if x.shape[2] >= k:
+        x = F.conv2d(x, g.view(1, 1, k, 1).repeat(C, 1, 1, 1), groups=C)
+    if x.shape[3] >= k:
+        x = F.conv2d(x, g.view(1, 1, 1, k).repeat(C, 1, 1, 1), groups=C)
+    return x
+
+
+def _ssim_terms(X, Y, data_range, g, K=(0.01, 0.03)):
+    C1, C2 = (K[0] * data_range) ** 2, (K[1] * data_range) ** 2
+    mu1, mu2 = _msssim_filter(X, g), _msssim_filter(Y, g)
+    mu1_sq, mu2_sq, mu1_mu2 = mu1 * mu1, mu2 * mu2, mu1 * mu2
+    s1 = _msssim_filter(X * X, g) - mu1_sq
+    s2 = _msssim_filter(Y * Y, g) - mu2_sq
+    s12 = _msssim_filter(X * Y, g) - mu1_mu2
+    cs_map = (2 * s12 + C2) / (s1 + s2 + C2)
+    ssim_map = ((2 * mu1_mu2 + C1) / (mu1_sq + mu2_sq + C1)) * cs_map
+    return ssim_map.flatten(2).mean(-1), cs_map.flatten(2).mean(-1)
+
+
+def ms_ssim(X, Y, data_range=255.0, size_average=True):
+    X, Y = X.float(), Y.float()
+    if min(X.shape[-2:]) <= (11 - 1) * 2 ** 4:
+        raise ValueError("Image size should be larger than 160 due to the 4 downsamplings in ms-ssim")
+    weights = torch.tensor([0.0448, 0.2856, 0.3001, 0.2363, 0.1333])
+    g = _msssim_window()
+    mcs = []
+    for i in range(5):
+        ssim_c, cs = _ssim_terms(X, Y, data_range, g)
+        if i < 4:
+            mcs.append(torch.relu(cs))
+            pad = [s % 2 for s in X.shape[2:]]
+            X = F.avg_pool2d(X, kernel_size=2, padding=pad)
+            Y = F.avg_pool2d(Y, kernel_size=2, padding=pad)
+    stack = torch.stack(mcs + [torch.relu(ssim_c)], dim=0)  # (level, batch, channel)
+    val = torch.prod(stack ** weights.view(-1, 1, 1), dim=0)
+    return val.mean() if size_average else val.mean(1)
