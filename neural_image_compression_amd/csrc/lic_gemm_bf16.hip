@@ -1,10 +1,10 @@
-// bf16-storage / fp32-accumulate variants of the implicit-GEMM kernels (BASELINE config 3).
-// Same structure as lic_gemm.hip -- A gathered through a double-buffered LDS tile, B (packed
-// weights) read straight from L2 into MFMA operand registers, 2x2 waves, LDS-staged epilogue --
-// on v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate): a K chunk is 32 bf16 = the same 64 bytes
-// per row as the fp32 kernel's 16 floats, so the memory-side instruction stream is identical and
-// only the matrix work per chunk shrinks (2 MFMAs of 32 cycles per tile instead of 8 of 64).
+// bf16-storage / fp32-accumulate variants of the implicit-GEMM kernels (BASELINE config 3) on
+// v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate).  igemm: the LDS-DMA structure of
+// lic_gemm.hip's default loop (both operands global -> LDS by `global_load_lds_dwordx4`, two
+// buffers, one barrier per chunk) with a 64-deep K chunk = 128-byte rows (whole cache lines; 4
+// MFMAs of 32 cycles per 32x32 tile per chunk), 2x2 waves, LDS-staged 16-byte epilogue.
 #include "lic_common.h"
+#include <type_traits>
 
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -26,12 +26,15 @@ __device__ __forceinline__ int fdivb(int n, FastDivB f) {
   return (int)(((unsigned long long)(unsigned)n * f.m) >> (31 + f.s));
 }
 
-constexpr int HB_BK = 32;            // bf16 elements per K chunk
-constexpr int HB_LDA = HB_BK + 8;    // LDS row pitch in bf16 (80 bytes)
+constexpr int HB_BK = 64;  // bf16 elements per K chunk (128-byte rows)
+
+__device__ __attribute__((aligned(16))) float g_lic_zero16h[4];  // DMA source of padding / tail lanes
+typedef const __attribute__((address_space(1))) void* lich_gptr_t;
+typedef __attribute__((address_space(3))) void* lich_lptr_t;
 
 struct IgemmHParams {
   const bf16_t* in;
-  const bf16_t* w;  // packed [tap][cpt][Npad][32] bf16
+  const bf16_t* w;  // packed [tap][cpt][Npad/32][4][64 lanes][8] bf16
   const float* bias;
   void* out;        // bf16 or fp32 (out_f32)
   bf16_t* out2;     // GDN norm (bf16)
@@ -58,16 +61,17 @@ __device__ __forceinline__ bf16x8 sq8(bf16x8 v) {
   return o;
 }
 
-template <int BM, int TN, bool FULLN>
+template <int BM, int TN>
 __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
   constexpr int BN = 64 * TN;
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int TM = WM / 32;
-  constexpr int APASS = BM / 64;
-  // A double buffer (bf16), later reused as the fp32 staging area of the epilogue (4 KiB per wave)
-  constexpr int SA_BYTES = (2 * BM * HB_LDA * 2 > 4 * 4096) ? 2 * BM * HB_LDA * 2 : 4 * 4096;
+  constexpr int APASS = BM / 32;              // 16-byte DMA pieces per thread per A tile
+  constexpr int BUF = (BM + BN) * HB_BK;      // bf16 elements of one (A tile, B panel) buffer
+  // two DMA buffers, later reused as the fp32 staging area of the epilogue (4 KiB per wave)
+  constexpr int SA_BYTES = (2 * BUF * 2 > 4 * 4096) ? 2 * BUF * 2 : 4 * 4096;
   __shared__ __attribute__((aligned(16))) char smem_raw[SA_BYTES];
-  bf16_t(*sA)[BM * HB_LDA] = reinterpret_cast<bf16_t(*)[BM * HB_LDA]>(smem_raw);
+  bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -93,12 +97,16 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
   const int py = (p.nphase > 1) ? phase / p.stride : 0;
   const int px = (p.nphase > 1) ? phase % p.stride : 0;
 
-  const int a_c8 = (tid & 3) * 8;  // bf16 channel offset of this thread's 16-byte piece
+  // A tile image [BM][64] bf16, packed 128-byte rows: thread t of pass j owns row t/8 + 32j,
+  // 16-byte slot t%8 = byte 16t + 4096j, the wave-linear order the DMA writes.  Rows r and r+2
+  // would share banks in a ds_read_b128 lane group, so slot s of row r holds K-octet s ^ ((r>>1)&7):
+  // applied to the per-lane SOURCE address here and to the fragment reads below.
+  const int gq = ((tid & 7) ^ ((tid >> 4) & 7)) * 8;  // this thread's logical channel offset in a chunk
   int a_base[APASS], a_hy[APASS], a_wx[APASS];
   bool a_ok[APASS];
 #pragma unroll
   for (int j = 0; j < APASS; ++j) {
-    const int prow = m0 + (tid >> 2) + 64 * j;
+    const int prow = m0 + (tid >> 3) + 32 * j;
     a_ok[j] = prow < P;
     const int pr = a_ok[j] ? prow : 0;
     const int b = fdivb(pr, p.dHW[phase]);
@@ -122,90 +130,63 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
     for (int b = 0; b < TN; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-  int n_live = 0;
-#pragma unroll
-  for (int b = 0; b < TN; ++b) n_live += ((n0 + wn0 + b * 32) < p.Npad) ? 1 : 0;
 
   const int ntaps = p.ntaps[phase];
   const int nchunks = ntaps * p.cpt;
-  bf16x8 ra[APASS];
-  bool ra_ok[APASS];
-  const bf16_t* wlane = p.w + ((long)(n0 + wn0 + li) * HB_BK + lh * 8);
-
   const int sgn = p.transposed ? -1 : 1;
   const int sh = (p.transposed && p.stride == 2) ? 1 : 0;
   const int last_tap = ntaps - 1, last_cb = p.cpt - 1;
-  auto load_a = [&](int tapi, int cb) {
-    const bool past = tapi > last_tap;
+  const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_lic_zero16h);
+  auto issue = [&](int tapi, int cb, int buf) {
+    const bool past = tapi > last_tap;  // cursor ran past the end: harmless duplicate DMA into the idle buffer
     const int tap = p.taps[phase][past ? last_tap : tapi];
+    const int cbb = past ? last_cb : cb;
     const int r = tap / p.kw, s = tap - r * p.kw;
-    const int ci = (past ? last_cb : cb) * HB_BK + a_c8;
+    const int ci = cbb * HB_BK + gq;
+    bf16_t* dstA = smem + buf * BUF;
 #pragma unroll
     for (int j = 0; j < APASS; ++j) {
       const int nh = a_hy[j] + sgn * r, nw = a_wx[j] + sgn * s;
       const int ih = nh >> sh, iw = nw >> sh;
       const bool ok = a_ok[j] && nh >= 0 && nw >= 0 && ih < p.Hi && iw < p.Wi && ci < p.Cin;
-      const int okm = -(int)ok;
-      const int pixi = (a_base[j] + ih * p.Wi + iw) & okm;
-      const int cc = ci & okm;
-      ra[j] = *reinterpret_cast<const bf16x8*>(p.in + ((long)pixi * p.in_ld + cc));
-      ra_ok[j] = ok;
+      const int okm = -(int)ok;  // selects, not a branch: the DMA stays in the MFMAs' basic block
+      const long off = (long)((a_base[j] + ih * p.Wi + iw) & okm) * p.in_ld + (ci & okm);
+      const bf16_t* src = (ok ? p.in : zsrc) + off;
+      __builtin_amdgcn_global_load_lds((lich_gptr_t)src, (lich_lptr_t)(dstA + j * 2048 + wave * 512), 16, 0, 0);
     }
+    const bf16_t* wsrc = p.w + ((long)tap * p.cpt + cbb) * p.Npad * HB_BK + (long)n0 * HB_BK + tid * 8;
+    bf16_t* dstB = dstA + BM * HB_BK;
+#pragma unroll
+    for (int j = 0; j < 2 * TN; ++j)
+      __builtin_amdgcn_global_load_lds((lich_gptr_t)(wsrc + j * 2048), (lich_lptr_t)(dstB + j * 2048 + wave * 512),
+                                       16, 0, 0);
   };
   const bool sq = p.prologue == 1;
-  auto store_a = [&](int buf) {
-#pragma unroll
-    for (int j = 0; j < APASS; ++j) {
-      bf16x8 v = ra[j];
-      if (!ra_ok[j]) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (bf16_t)0.0f;
-      }
-      if (sq) v = sq8(v);
-      *reinterpret_cast<bf16x8*>(&sA[buf][((tid >> 2) + 64 * j) * HB_LDA + a_c8]) = v;
-    }
-  };
-  int b_off[TN];
-#pragma unroll
-  for (int b = 0; b < TN; ++b) b_off[b] = (b < n_live ? b : (n_live > 0 ? n_live - 1 : 0)) * 32 * HB_BK;
-  if (n_live == 0) wlane = p.w + lh * 8;
-  auto load_b = [&](bf16x8 (&rb)[TN][2], int tapi, int cb) {
-    const bool past = tapi > last_tap;
-    const int tap = p.taps[phase][past ? last_tap : tapi];
-    const bf16_t* src = wlane + ((long)tap * p.cpt + (past ? last_cb : cb)) * p.Npad * HB_BK;
-#pragma unroll
-    for (int b = 0; b < TN; ++b) {
-      rb[b][0] = *reinterpret_cast<const bf16x8*>(src + b_off[b]);
-      rb[b][1] = *reinterpret_cast<const bf16x8*>(src + b_off[b] + 16);
-    }
-  };
-  auto compute = [&](int buf, const bf16x8 (&rb)[TN][2]) {
-    bf16x8 af[TM][2];
+  auto compute = [&](int buf) {
+    const bf16_t* bA = smem + buf * BUF;
+    const bf16_t* bB = bA + BM * HB_BK + (wn0 >> 5) * 2048 + lane * 8;
+    bf16x8 af[TM][4], bf[TN][4];
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
-      const bf16_t* src = &sA[buf][(wm0 + a * 32 + li) * HB_LDA + lh * 8];
-      af[a][0] = *reinterpret_cast<const bf16x8*>(src);
-      af[a][1] = *reinterpret_cast<const bf16x8*>(src + 16);
+      const int row = wm0 + a * 32 + li;
+      const int sw = (row >> 1) & 7;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        af[a][q] = *reinterpret_cast<const bf16x8*>(bA + row * HB_BK + (((q * 2 + lh) ^ sw) * 8));
+        if (sq) af[a][q] = sq8(af[a][q]);  // prologue 1 (GDN pool): square at the read
+      }
     }
-    if constexpr (FULLN) {
 #pragma unroll
-      for (int q = 0; q < 2; ++q)
+    for (int b = 0; b < TN; ++b)
 #pragma unroll
-        for (int b = 0; b < TN; ++b)
+      for (int q = 0; q < 4; ++q) bf[b][q] = *reinterpret_cast<const bf16x8*>(bB + (b * 4 + q) * 512);
 #pragma unroll
-          for (int a = 0; a < TM; ++a)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][q], rb[b][q], acc[a][b], 0, 0, 0);
-    } else {
+    for (int q = 0; q < 4; ++q)
 #pragma unroll
       for (int b = 0; b < TN; ++b)
-        if (b < n_live) {
 #pragma unroll
-          for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int a = 0; a < TM; ++a)
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][q], rb[b][q], acc[a][b], 0, 0, 0);
-        }
-    }
+        for (int a = 0; a < TM; ++a)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][q], bf[b][q], acc[a][b], 0, 0, 0);
   };
 
   int l_tap = 0, l_cb = 0;
@@ -215,33 +196,27 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
       ++l_tap;
     }
   };
-  bf16x8 rb0[TN][2], rb1[TN][2];
   if (nchunks > 0) {
-    load_a(0, 0);
-    load_b(rb0, 0, 0);
-    store_a(0);
-    __syncthreads();
+    // per chunk: __syncthreads (vmcnt(0): my DMA of chunk c landed; barrier: everyone's did and everyone
+    // is done reading chunk c-1) -> issue the DMA of chunk c+1 -> MFMAs of chunk c
+    issue(l_tap, l_cb, 0);
     advance();
-    load_a(l_tap, l_cb);
     int c = 0;
     for (; c + 1 < nchunks; c += 2) {
-      load_b(rb1, l_tap, l_cb);
-      store_a(1);
+      __syncthreads();
+      issue(l_tap, l_cb, 1);
       advance();
-      load_a(l_tap, l_cb);
-      compute(0, rb0);
+      compute(0);
+      __builtin_amdgcn_sched_barrier(0);  // keep the vmcnt(0)+barrier BEHIND this chunk's MFMAs
       __syncthreads();
-      load_b(rb0, l_tap, l_cb);
-      store_a(0);
+      issue(l_tap, l_cb, 0);
       advance();
-      load_a(l_tap, l_cb);
-      compute(1, rb1);
-      __syncthreads();
+      compute(1);
+      __builtin_amdgcn_sched_barrier(0);
     }
-    if (c < nchunks) {
-      compute(0, rb0);
-      __syncthreads();
-    }
+    __syncthreads();
+    if (c < nchunks) compute(0);
+    __syncthreads();  // the epilogue reuses the buffers
   }
 
   // ---- epilogue: stage each 32x32 fp32 tile through LDS; a lane then owns 8 consecutive
@@ -328,30 +303,34 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
 
 static bool al16h(const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
-// ---- weight packing to bf16: dst[tap][chunk][n][32], zero padded ----------------------------------
+// ---- weight packing to bf16: dst[tap][chunk][n/32][kstep][lane][8], zero padded (K to 64, N to 64).
+// Lane (col = lane&31, h = lane>>5) of a wave owns k = 16*kstep + 8h + e of column 32*tile + col:
+// the B fragment of one 32x32x16 MFMA is lane*16 B of one contiguous KiB.
 __global__ __launch_bounds__(256) void pack_weight_bf16_kernel(const float* src, bf16_t* dst, int taps, int K,
                                                                int N, int cpt, int Npad, long s_tap, long s_k,
                                                                long s_n) {
   const long total = (long)taps * cpt * Npad * HB_BK;
+  const int ntile = Npad >> 5;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int kk = (int)(i & (HB_BK - 1));
-    long t = i >> 5;
-    const int n = (int)(t % Npad);
-    t /= Npad;
+    const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), q = (int)((i >> 9) & 3);
+    long t = i >> 11;
+    const int tile = (int)(t % ntile);
+    t /= ntile;
     const int cb = (int)(t % cpt);
     const int tap = (int)(t / cpt);
-    const int k = cb * HB_BK + kk;
+    const int n = tile * 32 + (lane & 31);
+    const int k = cb * HB_BK + q * 16 + (lane >> 5) * 8 + e;
     dst[i] = (bf16_t)((k < K && n < N) ? src[tap * s_tap + k * s_k + n * s_n] : 0.0f);
   }
 }
 LIC_EXPORT int64_t lic_packed_weight_bf16_elems(int32_t taps, int32_t K, int32_t N) {
   if (taps <= 0 || K <= 0 || N <= 0) return 0;
-  return (int64_t)taps * ((K + HB_BK - 1) / HB_BK) * (((N + 31) / 32) * 32) * HB_BK;
+  return (int64_t)taps * ((K + HB_BK - 1) / HB_BK) * (((N + 63) / 64) * 64) * HB_BK;
 }
 LIC_EXPORT int lic_pack_weight_bf16(const float* src, void* dst, int32_t taps, int32_t K, int32_t N,
                                     int64_t s_tap, int64_t s_k, int64_t s_n, lic_stream_t stream) {
   if (!src || !dst || taps <= 0 || K <= 0 || N <= 0) return LIC_ERR_INVALID;
-  const int cpt = (K + HB_BK - 1) / HB_BK, Npad = ((N + 31) / 32) * 32;
+  const int cpt = (K + HB_BK - 1) / HB_BK, Npad = ((N + 63) / 64) * 64;
   const long total = (long)taps * cpt * Npad * HB_BK;
   hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, src,
                      (bf16_t*)dst, taps, K, N, cpt, Npad, (long)s_tap, (long)s_k, (long)s_n);
@@ -409,7 +388,7 @@ LIC_EXPORT int lic_igemm_bf16(const lic_igemm_desc* d, int32_t out_f32, lic_stre
   p.epilogue = epi;
   p.out_f32 = out_f32 ? 1 : 0;
   p.cpt = (d->Cin + HB_BK - 1) / HB_BK;
-  p.Npad = ((d->Cout + 31) / 32) * 32;
+  p.Npad = ((d->Cout + 63) / 64) * 64;  // whole 64-column wave pairs: every tile is full
   const uint32_t mask = d->tap_mask ? d->tap_mask : 0xFFFFFFFFu;
   p.nphase = (p.transposed && d->stride > 1) ? d->stride * d->stride : 1;
   long maxP = 0;
@@ -442,42 +421,17 @@ LIC_EXPORT int lic_igemm_bf16(const lic_igemm_desc* d, int32_t out_f32, lic_stre
   }
   if (maxP <= 0) return LIC_OK;
   if (maxP > 0x7FFFFFFFL / 2) return LIC_ERR_UNSUPPORTED;
-  static const int cand[6][2] = {{128, 3}, {64, 3}, {128, 2}, {64, 2}, {128, 1}, {64, 1}};
-  int best = 5;
-  long best_wg = -1;
-  bool found = false;
-  for (int pass = 0; pass < 2 && !found; ++pass)
-    for (int c = 0; c < 6; ++c) {
-      const int bm = cand[c][0], tn = cand[c][1];
-      if (p.Npad < 64 * tn && tn > 1 && p.Npad <= 64 * (tn - 1)) continue;
-      if (pass == 0 && p.Npad % (64 * tn) != 0) continue;
-      const long wgs = ((maxP + bm - 1) / bm) * ((p.Npad + 64 * tn - 1) / (64 * tn)) * p.nphase;
-      if (wgs >= 512) {
-        best = c;
-        best_wg = wgs;
-        found = true;
-        break;
-      }
-      if (wgs > best_wg) {
-        best = c;
-        best_wg = wgs;
-      }
-    }
-  const int BM = cand[best][0], TN = cand[best][1];
-  p.NT = (p.Npad + 64 * TN - 1) / (64 * TN);
+  // N tile: the widest of 192 / 128 / 64 columns that divides Npad; M tile: 128 rows while the grid
+  // keeps >= 512 workgroups
+  const int TN = (p.Npad % 192 == 0) ? 3 : ((p.Npad % 128 == 0) ? 2 : 1);
+  p.NT = p.Npad / (64 * TN);
+  const int BM = (((maxP + 127) / 128) * p.NT * p.nphase >= 512) ? 128 : 64;
   p.MT = (int)((maxP + BM - 1) / BM);
   const long nwg = (long)p.MT * p.NT * p.nphase;
   if (nwg > 0x7FFFFFFFL) return LIC_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)nwg), block(256);
-  const bool full = (p.Npad % (64 * TN)) == 0;
-#define LIC_IGEMMH_LAUNCH(bm, tn)                                                   \
-  do {                                                                              \
-    if (full)                                                                       \
-      hipLaunchKernelGGL((igemm_bf16_kernel<bm, tn, true>), grid, block, 0, s, p);  \
-    else                                                                            \
-      hipLaunchKernelGGL((igemm_bf16_kernel<bm, tn, false>), grid, block, 0, s, p); \
-  } while (0)
+#define LIC_IGEMMH_LAUNCH(bm, tn) hipLaunchKernelGGL((igemm_bf16_kernel<bm, tn>), grid, block, 0, s, p)
   if (BM == 128 && TN == 3)
     LIC_IGEMMH_LAUNCH(128, 3);
   else if (BM == 64 && TN == 3)
@@ -496,11 +450,19 @@ LIC_EXPORT int lic_igemm_bf16(const lic_igemm_desc* d, int32_t out_f32, lic_stre
 
 // ------------------------------------------------------------------------------------------------
 // wgrad (bf16 operands, fp32 slabs): R[tap][m][n] = sum_pix A[pix][m] * B[pix][n].
-// The MFMA wants 8 consecutive K (= pixels) per lane, but activations are pixel-major, so each
-// 32-pixel chunk is transposed on its way into LDS: a thread loads 8 channels of one pixel (16 B)
-// and scatters them as 2-byte stores into a channel-major tile [ch][32 pix (+8 pad)], whose
-// 8-pixel groups are XOR-swizzled by (ch/8)%4 (8-way -> 2-way store conflicts); fragments are then
-// plain ds_read_b128.
+// Both operands are activations stored pixel-major, but the MFMA wants 8 consecutive K (= pixels)
+// per lane.  Each chunk of BK pixels is DMA'd global -> LDS as it lies in memory
+// ([64-channel sub-tile][BK px][64 ch], 128-byte rows: thread t owns pixel t/8 (+32 per pass),
+// 16-byte slot t%8 = byte 16t, the wave-linear DMA order) and the transpose happens in the read:
+// `ds_read_b64_tr_b16` hands lane (channel i of a 16-channel group) 4 consecutive pixels of its
+// channel, two of them make one MFMA operand.  The 4 pixel rows of a transposed read are 128 B
+// apart (rows q and q+2 on the same banks), so the two 64-byte halves of a row are swapped on rows
+// with bit 1 set -- on the DMA's per-lane SOURCE address and in the read address.
+// Workgroup = 2x2 waves, wave tile = (32*TM) x (32*TN), BK = 32 pixels.  A chunk is only
+// TM*TN*2 MFMAs of 32 cycles per wave -- far shorter than an L2/HBM round trip -- so the DMA runs
+// TWO chunks ahead through a ring of three LDS buffers: `s_waitcnt vmcnt(N)` leaves the youngest
+// chunk's N DMAs in flight, a raw `s_barrier` (no fence: `__syncthreads()` would drain vmcnt to 0)
+// publishes the oldest one, and the buffer freed by the previous chunk is refilled at once.
 // ------------------------------------------------------------------------------------------------
 struct WgHOperand {
   const bf16_t* ptr;
@@ -519,15 +481,22 @@ struct WgradHParams {
   long Ps;
   FastDivB dHW, dW;
 };
-constexpr int WH_BK = 32;
-constexpr int WH_LD = WH_BK + 8;
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
 
-template <int TM, int TN>
-__global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradHParams p) {
+constexpr int WH_BK = 32;
+
+// SQB: the column operand is squared at the read (GDN d-gamma: t^T . x^2)
+template <int TM, int TN, bool SQB = false>
+__global__ __launch_bounds__(256, 2) void wgrad_bf16_kernel(const WgradHParams p) {
+  constexpr int BK = WH_BK;
+  constexpr int NPASS = BK / 32;               // DMA pieces per thread per sub-tile
+  constexpr int SUB = BK * 64;                 // bf16 elements of one [BK px][64 ch] sub-tile
+  constexpr int NS = TM + TN;
+  constexpr int NL = NS * NPASS;               // DMA instructions per thread per chunk
   constexpr int BMt = 64 * TM, BNt = 64 * TN;
   constexpr int WM = BMt / 2, WN = BNt / 2;
-  __shared__ __attribute__((aligned(16))) bf16_t sA[2][BMt * WH_LD];
-  __shared__ __attribute__((aligned(16))) bf16_t sB[2][BNt * WH_LD];
+  __shared__ __attribute__((aligned(16))) bf16_t smem[3][NS][SUB];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
@@ -548,11 +517,7 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradHParams p) {
   const int c_begin = split * p.chunks_per_split;
   const int c_end = min(p.nchunks, c_begin + p.chunks_per_split);
   const int nloc = c_end - c_begin;
-  int m_live = 0, n_live = 0;
-#pragma unroll
-  for (int a = 0; a < TM; ++a) m_live += ((m0 + wm0 + a * 32) < p.row.C) ? 1 : 0;
-#pragma unroll
-  for (int b = 0; b < TN; ++b) n_live += ((n0 + wn0 + b * 32) < p.col.C) ? 1 : 0;
+
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int a = 0; a < TM; ++a)
@@ -561,114 +526,149 @@ __global__ __launch_bounds__(256) void wgrad_bf16_kernel(const WgradHParams p) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[a][b][q] = 0.0f;
 
-  const int kr = tid >> 3, l8 = tid & 7;     // pixel row of the chunk, channel octet
-  const int swz = (l8 & 3) * 8;              // store-side swizzle of this thread's channels
-  const int kpos = kr ^ swz;                 // where pixel kr lands inside a channel row
-  bf16x8 ra[TM], rb[TN];
-  bool ra_ok[TM], rb_ok[TN];
-  auto load_chunk = [&](int c) {
-    const long pk = (long)(c < c_end ? c : c_end - 1) * WH_BK + kr;
-    const bool inb = pk < p.Ps;
-    const long pix = inb ? pk : 0;
-    const int b = fdivb((int)pix, p.dHW);
-    const int rem = (int)pix - b * p.Hs * p.Ws;
-    const int hs = fdivb(rem, p.dW), ws = rem - hs * p.Ws;
-    const int hl = hs * p.stride - p.pad + r, wl = ws * p.stride - p.pad + s;
-    const bool gok = inb && hl >= 0 && wl >= 0 && hl < p.Hl && wl < p.Wl;
-    const long gpix = ((long)b * p.Hl + hl) * p.Wl + wl;
-    auto load_op = [&](const WgHOperand& op, int ch, bf16x8& v, bool& okr) {
-      bool ok = (op.gathered ? gok : inb) && ch < op.C;
-      const long px = op.gathered ? gpix : pix;
-      v = *reinterpret_cast<const bf16x8*>(op.ptr + (ok ? px * op.ld + ch : 0L));
-      okr = ok;
-    };
+  // DMA slots: thread t owns pixel row t/8 (+32 per pass) and physical 16-byte slot t%8 of every
+  // sub-tile; it fetches logical slot (t%8) ^ 4*bit1(row)
+  const int kr = tid >> 3;
+  const int c8 = (((tid & 7) ^ (((tid >> 4) & 1) << 2))) * 8;
+  const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_lic_zero16h);
+  auto issue = [&](int c, int buf) {
+    const int cc = c < c_end ? c : c_end - 1;  // past the end: harmless duplicate DMA into the idle buffer
 #pragma unroll
-    for (int j = 0; j < TM; ++j) load_op(p.row, m0 + l8 * 8 + 64 * j, ra[j], ra_ok[j]);
+    for (int j = 0; j < NPASS; ++j) {
+      const long pk = (long)cc * BK + kr + 32 * j;
+      const bool inb = pk < p.Ps;
+      const int pix = inb ? (int)pk : 0;
+      const int b = fdivb(pix, p.dHW);
+      const int rem = pix - b * p.Hs * p.Ws;
+      const int hs = fdivb(rem, p.dW), ws = rem - hs * p.Ws;
+      const int hl = hs * p.stride - p.pad + r, wl = ws * p.stride - p.pad + s;
+      const bool gok = inb && hl >= 0 && wl >= 0 && hl < p.Hl && wl < p.Wl;
+      const long gpix = ((long)b * p.Hl + hl) * p.Wl + wl;
+      const bool rok = p.row.gathered ? gok : inb, cok = p.col.gathered ? gok : inb;
+      const long rpx = (p.row.gathered ? gpix : (long)pix), cpx = (p.col.gathered ? gpix : (long)pix);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) load_op(p.col, n0 + l8 * 8 + 64 * j, rb[j], rb_ok[j]);
-  };
-  const bool sqa = p.row.sq != 0, sqb = p.col.sq != 0;
-  auto store_chunk = [&](int buf) {
+      for (int t = 0; t < TM; ++t) {
+        const int ch = m0 + 64 * t + c8;
+        const bool ok = rok && ch < p.row.C;
+        const bf16_t* src = ok ? p.row.ptr + rpx * p.row.ld + ch : zsrc;
+        __builtin_amdgcn_global_load_lds((lich_gptr_t)src, (lich_lptr_t)&smem[buf][t][j * 2048 + wave * 512], 16, 0,
+                                         0);
+      }
 #pragma unroll
-    for (int j = 0; j < TM; ++j) {
-      bf16x8 v = ra[j];
-      if (sqa) v = sq8(v);
-#pragma unroll
-      for (int e = 0; e < 8; ++e)
-        sA[buf][(l8 * 8 + 64 * j + e) * WH_LD + kpos] = ra_ok[j] ? v[e] : (bf16_t)0.0f;
-    }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      bf16x8 v = rb[j];
-      if (sqb) v = sq8(v);
-#pragma unroll
-      for (int e = 0; e < 8; ++e)
-        sB[buf][(l8 * 8 + 64 * j + e) * WH_LD + kpos] = rb_ok[j] ? v[e] : (bf16_t)0.0f;
+      for (int t = 0; t < TN; ++t) {
+        const int ch = n0 + 64 * t + c8;
+        const bool ok = cok && ch < p.col.C;
+        const bf16_t* src = ok ? p.col.ptr + cpx * p.col.ld + ch : zsrc;
+        __builtin_amdgcn_global_load_lds((lich_gptr_t)src, (lich_lptr_t)&smem[buf][TM + t][j * 2048 + wave * 512],
+                                         16, 0, 0);
+      }
     }
   };
-  auto compute = [&](int buf) {
-    bf16x8 af[TM][2], bf[TN][2];
+  // transposed-read lane address inside a sub-tile, for channel half (0 / 32): lane 4q+pp of the
+  // 16-lane group g supplies row (8*lh + q), channels 32*half + 16*(g&1) + 4*pp .. +3.
+  // The reads are inline asm: hipcc puts `s_waitcnt vmcnt(0)` in front of the tr16 builtin whenever
+  // an LDS-DMA is in flight (it cannot see that the ring buffers are disjoint), which would undo
+  // the two-chunk prefetch; with asm the lgkmcnt wait is ours to place (one per K step).
+  const int tq = (lane >> 2) & 3, tp = lane & 3, tg = (lane >> 4) & 1;
+  unsigned tr_addr[2];  // LDS byte address of this lane's element in sub-tile 0 of buffer 0
+  {
+    const unsigned base = (unsigned)(size_t)(__attribute__((address_space(3))) void*)&smem[0][0][0];
 #pragma unroll
-    for (int a = 0; a < TM; ++a) {
-      const int ch = wm0 + a * 32 + li;
-      const int sw = (ch >> 3) & 3;
-#pragma unroll
-      for (int q = 0; q < 2; ++q)
-        af[a][q] = *reinterpret_cast<const bf16x8*>(&sA[buf][ch * WH_LD + (((2 * q + lh) ^ sw) * 8)]);
+    for (int half = 0; half < 2; ++half) {
+      const int cs = 32 * half + 16 * tg + 4 * tp;
+      const int slot = (cs >> 3) ^ ((tq >> 1) << 2);
+      tr_addr[half] = base + 2u * (unsigned)((8 * lh + tq) * 64 + slot * 8 + (cs & 7));
     }
+  }
+  auto compute = [&](auto bufc) {
+    constexpr int buf = decltype(bufc)::value;
 #pragma unroll
-    for (int b = 0; b < TN; ++b) {
-      const int ch = wn0 + b * 32 + li;
-      const int sw = (ch >> 3) & 3;
+    for (int ks = 0; ks < BK / 16; ++ks) {
+      // pixels 16*ks + 8*lh + {0..3} (lo) and {4..7} (hi) of this lane's channel, per 32-channel tile
+      unsigned long long lo[NS], hi[NS];
 #pragma unroll
-      for (int q = 0; q < 2; ++q)
-        bf[b][q] = *reinterpret_cast<const bf16x8*>(&sB[buf][ch * WH_LD + (((2 * q + lh) ^ sw) * 8)]);
-    }
+      for (int t = 0; t < TM + TN; ++t) {
+        const int ch = t < TM ? wm0 + t * 32 : wn0 + (t - TM) * 32;  // wave-uniform
+        const int sub = t < TM ? (ch >> 6) : TM + (ch >> 6);
+        const unsigned addr = tr_addr[(ch >> 5) & 1] + 2u * (unsigned)((buf * NS + sub) * SUB + 16 * ks * 64);
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(lo[t]) : "v"(addr));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:512" : "=v"(hi[t]) : "v"(addr));
+      }
+      // one wait for the K step; the operands pass through it so the MFMAs cannot be scheduled above
+      if constexpr (NS == 2)
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]));
+      else if constexpr (NS == 3)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]));
+      else if constexpr (NS == 4)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]), "+v"(lo[3]),
+                       "+v"(hi[3]));
+      else if constexpr (NS == 5)
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]), "+v"(lo[3]),
+                       "+v"(hi[3]), "+v"(lo[4]), "+v"(hi[4]));
+      else
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(lo[0]), "+v"(hi[0]), "+v"(lo[1]), "+v"(hi[1]), "+v"(lo[2]), "+v"(hi[2]), "+v"(lo[3]),
+                       "+v"(hi[3]), "+v"(lo[4]), "+v"(hi[4]), "+v"(lo[5]), "+v"(hi[5]));
+      bf16x8 fr[NS];
 #pragma unroll
-    for (int a = 0; a < TM; ++a)
-      if (a < m_live) {
+      for (int t = 0; t < NS; ++t) {
+        struct {
+          unsigned long long a, b;
+        } pr{lo[t], hi[t]};
+        fr[t] = __builtin_bit_cast(bf16x8, pr);
+        if constexpr (SQB)
+          if (t >= TM) fr[t] = sq8(fr[t]);
+      }
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
 #pragma unroll
         for (int b = 0; b < TN; ++b)
-          if (b < n_live) {
-#pragma unroll
-            for (int q = 0; q < 2; ++q)
-              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][q], bf[b][q], acc[a][b], 0, 0, 0);
-          }
-      }
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[a], fr[TM + b], acc[a][b], 0, 0, 0);
+    }
   };
+
   if (nloc > 0) {
-    load_chunk(c_begin);
-    store_chunk(0);
-    __syncthreads();
-    load_chunk(c_begin + 1);
+    // Ring of three buffers.  At the top of iteration c the DMAs of chunks c and c+1 are in flight
+    // (c+1 younger).  vmcnt(NL) retires mine of chunk c; the barrier tells me everyone's landed
+    // and that everyone finished reading chunk c-1, whose buffer takes chunk c+2.
+    // (Buffer indices are compile-time constants -- the ring is unrolled by three -- because hipcc
+    // waits vmcnt(0) in front of any LDS read it cannot prove disjoint from an LDS-DMA in flight.)
+    issue(c_begin, 0);
+    issue(c_begin + 1, 1);
+    auto step = [&](int c, auto cur, auto fill) {
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(NL) : "memory");
+      issue(c_begin + c + 2, decltype(fill)::value);
+      compute(cur);
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
     int c = 0;
-    for (; c + 1 < nloc; c += 2) {
-      store_chunk(1);
-      load_chunk(c_begin + c + 2);
-      compute(0);
-      __syncthreads();
-      store_chunk(0);
-      load_chunk(c_begin + c + 3);
-      compute(1);
-      __syncthreads();
+    for (; c + 2 < nloc; c += 3) {
+      step(c, I0{}, I2{});
+      step(c + 1, I1{}, I0{});
+      step(c + 2, I2{}, I1{});
     }
-    if (c < nloc) {
-      compute(0);
-      __syncthreads();
-    }
+    if (c < nloc) step(c, I0{}, I2{});
+    if (c + 1 < nloc) step(c + 1, I1{}, I0{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // duplicate tail DMAs must land before the wave ends
   }
   float* slab = p.slabs + ((long)split * p.ntaps + tap) * p.row.C * p.col.C;
 #pragma unroll
   for (int a = 0; a < TM; ++a)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int m = m0 + wm0 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
-      if (m >= p.row.C) continue;
+    for (int b = 0; b < TN; ++b) {
+      const int n = n0 + wn0 + b * 32 + li;
 #pragma unroll
-      for (int b = 0; b < TN; ++b) {
-        const int n = n0 + wn0 + b * 32 + li;
-        if (n < p.col.C) slab[(long)m * p.col.C + n] = acc[a][b][q];
+      for (int q = 0; q < 16; ++q) {
+        const int m = m0 + wm0 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
+        if (m < p.row.C && n < p.col.C) slab[(long)m * p.col.C + n] = acc[a][b][q];
       }
+      __builtin_amdgcn_sched_barrier(0);  // one accumulator tile at a time: bounds the live VGPRs
     }
 }
 
@@ -698,15 +698,20 @@ static int wgh_plan(const lic_wgrad_desc* d, WgHPlan* pl) {
   pl->Cm = d->g_is_row ? d->Cg : d->Cp;
   pl->Cn = d->g_is_row ? d->Cp : d->Cg;
   pl->ntaps = d->kh * d->kw;
-  pl->TM = (pl->Cm > 64 && pl->Cm % 128 == 0) ? 2 : 1;
-  pl->TN = pl->Cn > 128 ? 3 : (pl->Cn > 64 ? 2 : 1);
+  // widest tile (in 64-channel units, at most 3) that divides the channel count's 64-padding
+  auto pick = [](int C) {
+    const int u = (C + 63) / 64;
+    return u % 3 == 0 ? 3 : (u % 2 == 0 ? 2 : (u == 1 ? 1 : (u > 4 ? 3 : 2)));
+  };
+  pl->TM = pick(pl->Cm);
+  pl->TN = pick(pl->Cn);
   pl->MTt = (pl->Cm + 64 * pl->TM - 1) / (64 * pl->TM);
   pl->NTt = (pl->Cn + 64 * pl->TN - 1) / (64 * pl->TN);
   const long Ps = (long)d->B * d->Hs * d->Ws;
   pl->nchunks = (int)((Ps + WH_BK - 1) / WH_BK);
   const long base = (long)pl->MTt * pl->NTt * pl->ntaps;
   long sk = (1024 + base - 1) / base;
-  const long max_sk = (pl->nchunks + 15) / 16;
+  const long max_sk = (pl->nchunks + 15) / 16;  // at least 16 chunks (512 pixels) per split
   if (sk > max_sk) sk = max_sk;
   if (sk < 1) sk = 1;
   if (sk > 256) sk = 256;
@@ -765,18 +770,26 @@ LIC_EXPORT int lic_wgrad_bf16(const lic_wgrad_desc* d, void* workspace, size_t w
   p.dW = make_fastdivb((unsigned)d->Ws);
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(pl.MTt * pl.NTt * pl.ntaps * pl.splitk), block(256);
-  if (pl.TM == 2 && pl.TN == 3)
-    hipLaunchKernelGGL((wgrad_bf16_kernel<2, 3>), grid, block, 0, s, p);
-  else if (pl.TM == 2 && pl.TN == 2)
-    hipLaunchKernelGGL((wgrad_bf16_kernel<2, 2>), grid, block, 0, s, p);
-  else if (pl.TM == 2 && pl.TN == 1)
-    hipLaunchKernelGGL((wgrad_bf16_kernel<2, 1>), grid, block, 0, s, p);
-  else if (pl.TM == 1 && pl.TN == 3)
-    hipLaunchKernelGGL((wgrad_bf16_kernel<1, 3>), grid, block, 0, s, p);
-  else if (pl.TM == 1 && pl.TN == 2)
-    hipLaunchKernelGGL((wgrad_bf16_kernel<1, 2>), grid, block, 0, s, p);
-  else
-    hipLaunchKernelGGL((wgrad_bf16_kernel<1, 1>), grid, block, 0, s, p);
+  if (p.row.sq) return LIC_ERR_UNSUPPORTED;  // only the column operand can be squared (GDN d-gamma)
+  if (p.col.sq) {
+    if (pl.TM != pl.TN) return LIC_ERR_UNSUPPORTED;  // C x C products only
+    if (pl.TM == 1) hipLaunchKernelGGL((wgrad_bf16_kernel<1, 1, true>), grid, block, 0, s, p);
+    if (pl.TM == 2) hipLaunchKernelGGL((wgrad_bf16_kernel<2, 2, true>), grid, block, 0, s, p);
+    if (pl.TM == 3) hipLaunchKernelGGL((wgrad_bf16_kernel<3, 3, true>), grid, block, 0, s, p);
+  } else {
+#define LIC_WGH(tm, tn) \
+  if (pl.TM == tm && pl.TN == tn) hipLaunchKernelGGL((wgrad_bf16_kernel<tm, tn>), grid, block, 0, s, p)
+  LIC_WGH(1, 1);
+  LIC_WGH(1, 2);
+  LIC_WGH(1, 3);
+  LIC_WGH(2, 1);
+  LIC_WGH(2, 2);
+  LIC_WGH(2, 3);
+  LIC_WGH(3, 1);
+  LIC_WGH(3, 2);
+  LIC_WGH(3, 3);
+#undef LIC_WGH
+  }
   rc = lic_check_launch();
   if (rc != LIC_OK) return rc;
   const long total = (long)pl.ntaps * pl.Cm * pl.Cn;
