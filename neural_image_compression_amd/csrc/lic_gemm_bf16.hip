@@ -687,6 +687,8 @@ __global__ __launch_bounds__(256) void wgrad_bf16_reduce_kernel(const float* sla
   }
 }
 
+long lic_pick_splits(long base, long slots, long max_sk);  // lic_gemm.hip
+
 struct WgHPlan {
   int TM, TN, MTt, NTt, ntaps, nchunks, splitk, cps, Cm, Cn;
 };
@@ -710,13 +712,9 @@ static int wgh_plan(const lic_wgrad_desc* d, WgHPlan* pl) {
   const long Ps = (long)d->B * d->Hs * d->Ws;
   pl->nchunks = (int)((Ps + WH_BK - 1) / WH_BK);
   const long base = (long)pl->MTt * pl->NTt * pl->ntaps;
-  long sk = (1024 + base - 1) / base;
   const long max_sk = (pl->nchunks + 15) / 16;  // at least 16 chunks (512 pixels) per split
-  if (sk > max_sk) sk = max_sk;
-  if (sk < 1) sk = 1;
-  if (sk > 256) sk = 256;
-  if (sk > 8) sk = (sk + 7) & ~7L;
-  if (sk > max_sk) sk = max_sk;
+  // resident workgroups per CU: 2 for the 5-6 sub-tile variants (registers / 72 KiB LDS), else 3
+  const long sk = lic_pick_splits(base, 256L * (pl->TM + pl->TN >= 5 ? 2 : 3), max_sk);
   pl->cps = (int)((pl->nchunks + sk - 1) / sk);
   pl->splitk = (pl->nchunks + pl->cps - 1) / pl->cps;
   return LIC_OK;
