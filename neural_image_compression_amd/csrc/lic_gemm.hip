@@ -1419,15 +1419,17 @@ static int wg_plan(const lic_wgrad_desc* d, WgPlan* pl) {
   const long Ps = (long)d->B * d->Hs * d->Ws;
   pl->nchunks = (int)((Ps + WG_BK - 1) / WG_BK);
   const long base = (long)pl->MTt * pl->NTt * pl->ntaps;
-  // ~1024 workgroups, whole splits per XCD.  (Measured against whole-round counts from
-  // lic_pick_splits, which the bf16 kernels use: 75 x 16 = 1200 workgroups beat 75 x 13 = 975 by
-  // 10 % here -- the 8-aligned split count keeps each XCD's L2 on its own pixel ranges.)
-  long sk = (1024 + base - 1) / base;
+  // ~2.5 rounds of the 1024 resident workgroups, whole splits per XCD.  Measured on the big layers
+  // (75 workgroups per split): 16 splits 2.47 ms, 40 splits 2.31 ms, 64 splits 2.28 ms -- shorter
+  // workgroups even out the tail -- while the slab reduction grows by ~1.7 us per split; whole-round
+  // counts that are not multiples of 8 (13 splits) lose the XCD-local L2 reuse and were no better.
+  long sk = (2560 + base - 1) / base;
   const long max_sk = (pl->nchunks + 15) / 16;  // at least 16 chunks (256 pixels) per split
   if (sk > max_sk) sk = max_sk;
   if (sk < 1) sk = 1;
   if (sk > 256) sk = 256;
   if (sk > 8) sk = (sk + 7) & ~7L;  // whole splits per XCD (see the kernel's remap)
+  if (const char* e = getenv("LIC_WGRAD_SPLITS")) sk = atol(e) > 0 ? atol(e) : sk;  // tuning aid
   if (sk > max_sk) sk = max_sk;
   pl->cps = (int)((pl->nchunks + sk - 1) / sk);
   pl->splitk = (pl->nchunks + pl->cps - 1) / pl->cps;
