@@ -264,6 +264,23 @@ int lic_gdn_dnorm_bf16(const void* g, const void* x, const void* norm, void* t, 
 
 /* ---- misc ---------------------------------------------------------------------------------- */
 /* ------------------------------------------------------------------------------------------
+ * SURVEY 8(f).2 -- tables for an entropy coder (the reference has none), built on the
+ * device from the same distributions the likelihood entries evaluate and consumed by the host range
+ * coder of include/lic_codec.h.  A table has S symbols (index i <-> integer value lo + i) and S+1
+ * uint32 entries  cum[i] = floor(F_i * (65536 - S)) + i  with F_0 = 0, F_S = 1 and
+ * F_i = CDF(lo + i - 0.5): cum[0] = 0, cum[S] = 65536, every symbol keeps frequency >= 1; indices 0
+ * and S-1 carry the tails (the coder escapes out-of-window values through them).
+ *   lic_factorized_cdf_tables: out[C][S+1], F = sigmoid(L_c(.))         (EntropyModels.py:153-184)
+ *   lic_gmm_cdf_tables: per latent element e of [P][M]: center[e] = rint(sum_k w_k mu_k), window
+ *     lo = center - W, S = 2W+1, out[P*M][S+1], F = sum_k w_k Phi((x - mu_k)/sigma_k); `params` as
+ *     lic_gmm_likelihood_fwd                                    (EntropyModels.py:192-233, utils.py:6-8)
+ * ------------------------------------------------------------------------------------------ */
+int lic_factorized_cdf_tables(const float* fe_params, int32_t C, int32_t lo, int32_t S, uint32_t* out,
+                              lic_stream_t stream);
+int lic_gmm_cdf_tables(const float* params, int64_t P, int32_t M, int32_t K, int32_t W, int32_t* center,
+                       uint32_t* out, lic_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * SURVEY 8(f).1 -- evaluation metric on the device.
  * Multi-scale SSIM exactly as the reference's evaluator calls it (Evaluator.py:7,38,45:
  * `ms_ssim(recon, orig, data_range=1.0, size_average=True)` of the third-party pytorch-msssim==0.2.1,

@@ -87,6 +87,8 @@ SIGNATURES = {
     "lic_gdn_dnorm_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "lic_igemm_fused_gdn_supported": (C.c_int, [_i32, _i32]),
     "lic_igemm_fused_gdn_preferred": (C.c_int, [C.POINTER(IgemmDesc)]),
+    "lic_factorized_cdf_tables": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
+    "lic_gmm_cdf_tables": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "lic_msssim_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "lic_msssim": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _f32, _vp, _vp, _vp, _sz,
                              _vp]),

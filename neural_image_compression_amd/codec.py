@@ -1,0 +1,172 @@
+"""Entropy coding of the latents.  The reference only ESTIMATES bits
+(RateDistortionLoss.py:13-18; no coder or bitstream exists there); this module turns
+the same distributions into real byte strings and checks that estimate against them.
+
+Division of labour: the MI355X builds the 16-bit cumulative tables for every latent element in
+parallel (`lic_factorized_cdf_tables` from the factorised prior's per-channel CDF,
+EntropyModels.py:153-184; `lic_gmm_cdf_tables` from the Gaussian / mixture parameters,
+EntropyModels.py:192-233) and the serial range coder runs on the host CPU
+(`liblic_codec.so`, include/lic_codec.h), as the north star prescribes.
+
+Scope of this round: `compress` (y and z streams), `decompress_z` (the hyper-latent has a
+parameter-free prior, so it decodes without context) and `decode_y_with_tables` (decodes y from the
+tables the encoder used -- the coder's inverse).  The raster-order loop that rebuilds those tables
+from already-decoded pixels through the masked 5x5 context model is the serial step that remains.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import functional as F_
+
+_CODEC = None
+
+
+class CodecError(RuntimeError):
+    pass
+
+
+def _codec():
+    global _CODEC
+    if _CODEC is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "liblic_codec.so")
+        if not os.path.exists(path):
+            raise CodecError(f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'`")
+        lib = C.CDLL(path)
+        u32p, i32p, u8p = C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.POINTER(C.c_uint8)
+        lib.lic_rc_bound.restype, lib.lic_rc_bound.argtypes = C.c_size_t, [C.c_int64]
+        lib.lic_rc_encode.restype = C.c_int
+        lib.lic_rc_encode.argtypes = [u32p, i32p, C.c_int32, i32p, C.c_int64, u8p, C.c_size_t, C.POINTER(C.c_size_t)]
+        lib.lic_rc_decode.restype = C.c_int
+        lib.lic_rc_decode.argtypes = [u8p, C.c_size_t, u32p, i32p, C.c_int32, C.c_int64, i32p]
+        lib.lic_rc_ideal_bits.restype = C.c_double
+        lib.lic_rc_ideal_bits.argtypes = [u32p, i32p, C.c_int32, i32p, C.c_int64]
+        lib.lic_codec_version.restype = C.c_int
+        _CODEC = lib
+    return _CODEC
+
+
+def _p(a: np.ndarray, t):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def rc_encode(tables: np.ndarray, idx: np.ndarray, table_of: np.ndarray = None) -> bytes:
+    """tables [T][S+1] uint32, idx [n] int32 (value - window_lo), table_of [n] int32 or None (T == n)."""
+    tables = np.ascontiguousarray(tables, np.uint32)
+    idx = np.ascontiguousarray(idx, np.int32).ravel()
+    tof = None if table_of is None else np.ascontiguousarray(table_of, np.int32).ravel()
+    S = tables.shape[-1] - 1
+    lib = _codec()
+    cap = lib.lic_rc_bound(idx.size)
+    out = np.empty(cap, np.uint8)
+    nb = C.c_size_t(0)
+    rc = lib.lic_rc_encode(_p(tables, C.c_uint32), _p(tof, C.c_int32), S, _p(idx, C.c_int32), idx.size,
+                           _p(out, C.c_uint8), cap, C.byref(nb))
+    if rc != 0:
+        raise CodecError(f"lic_rc_encode failed with status {rc}")
+    return out[:nb.value].tobytes()
+
+
+def rc_decode(data: bytes, tables: np.ndarray, n: int, table_of: np.ndarray = None) -> np.ndarray:
+    tables = np.ascontiguousarray(tables, np.uint32)
+    tof = None if table_of is None else np.ascontiguousarray(table_of, np.int32).ravel()
+    S = tables.shape[-1] - 1
+    buf = np.frombuffer(data, np.uint8)
+    out = np.empty(n, np.int32)
+    rc = _codec().lic_rc_decode(_p(buf, C.c_uint8), buf.size, _p(tables, C.c_uint32), _p(tof, C.c_int32), S, n,
+                                _p(out, C.c_int32))
+    if rc != 0:
+        raise CodecError(f"lic_rc_decode failed with status {rc}")
+    return out
+
+
+def rc_ideal_bits(tables: np.ndarray, idx: np.ndarray, table_of: np.ndarray = None) -> float:
+    tables = np.ascontiguousarray(tables, np.uint32)
+    idx = np.ascontiguousarray(idx, np.int32).ravel()
+    tof = None if table_of is None else np.ascontiguousarray(table_of, np.int32).ravel()
+    return float(_codec().lic_rc_ideal_bits(_p(tables, C.c_uint32), _p(tof, C.c_int32), tables.shape[-1] - 1,
+                                            _p(idx, C.c_int32), idx.size))
+
+
+# ---- device side: tables --------------------------------------------------------------------
+def factorized_tables(fe_model, lo: int, S: int) -> torch.Tensor:
+    """[C][S+1] uint32 (as int64-safe torch.int32 view) for symbols lo .. lo+S-1 of every channel."""
+    params = fe_model.packed_params().detach().contiguous()
+    Cc = params.shape[0]
+    out = torch.empty((Cc, S + 1), device=params.device, dtype=torch.int32)
+    L.check(L.load().lic_factorized_cdf_tables(F_._ptr(params), Cc, int(lo), int(S), F_._ptr(out), F_._stream()),
+            "lic_factorized_cdf_tables")
+    return out
+
+
+def gmm_tables(act: torch.Tensor, M: int, K: int, W: int):
+    """act: the packed activated parameters [B,G*K*M,h,w] (EntropyParameters.packed); returns
+    (center [B,h,w,M] int32, tables [B*h*w*M][2W+2] int32-viewed uint32)."""
+    a = F_._nhwc(act.detach())  # [B,h,w,G*K*M] contiguous
+    P = a.numel() // a.shape[-1]
+    center = torch.empty((P, M), device=a.device, dtype=torch.int32)
+    tables = torch.empty((P * M, 2 * W + 2), device=a.device, dtype=torch.int32)
+    L.check(L.load().lic_gmm_cdf_tables(F_._ptr(a), P, M, K, int(W), F_._ptr(center), F_._ptr(tables), F_._stream()),
+            "lic_gmm_cdf_tables")
+    return center, tables
+
+
+class LatentCodec:
+    """compress / decompress the (y, z) latents of a JointAutoregressiveHierarchical /
+    HierarchicalMixtureResidual model.  `z_lo`, `z_S`: symbol window of the hyper-latent tables;
+    `y_W`: half-width of the per-element window around the mixture mean."""
+
+    def __init__(self, model, z_lo: int = -64, z_S: int = 129, y_W: int = 32):
+        self.model, self.z_lo, self.z_S, self.y_W = model, int(z_lo), int(z_S), int(y_W)
+
+    @torch.no_grad()
+    def compress(self, x: torch.Tensor) -> Dict:
+        m = self.model
+        out = m.analysis_hyperprior(x, training=False, with_packed_params=True)
+        y_in, z_in = out["y_in"], out["z_in"]                      # NCHW-logical, NHWC-physical, integer valued
+        B, M, h, w = y_in.shape
+        zt = factorized_tables(m.factorized_entropy_model, self.z_lo, self.z_S).cpu().numpy().view(np.uint32)
+        z_nhwc = z_in.permute(0, 2, 3, 1).contiguous()
+        z_idx = (z_nhwc.round().to(torch.int32) - self.z_lo).cpu().numpy().ravel()
+        z_tab = np.tile(np.arange(M, dtype=np.int32), z_idx.size // M)
+        z_bytes = rc_encode(zt, z_idx, z_tab)
+        act = out["_act"]
+        center, yt = gmm_tables(act, M, m.K, self.y_W)
+        y_nhwc = y_in.permute(0, 2, 3, 1).contiguous().round().to(torch.int32)
+        y_idx = (y_nhwc.reshape(-1, M) - center + self.y_W).cpu().numpy().ravel()
+        yt_h = yt.cpu().numpy().view(np.uint32)
+        y_bytes = rc_encode(yt_h, y_idx)
+        npix = x.shape[0] * x.shape[2] * x.shape[3]
+        return {"strings": {"y": y_bytes, "z": z_bytes}, "shape": (B, M, h, w),
+                "z_shape": tuple(z_in.shape),
+                "bpp_coded_y": 8.0 * len(y_bytes) / npix, "bpp_coded_z": 8.0 * len(z_bytes) / npix,
+                "bpp_ideal_y": rc_ideal_bits(yt_h, y_idx) / npix, "bpp_ideal_z": rc_ideal_bits(zt, z_idx, z_tab) / npix,
+                "bpp_est_y": float(-out["logp_y"].double().sum() / np.log(2.0) / npix),
+                "bpp_est_z": float(-out["logp_z"].double().sum() / np.log(2.0) / npix),
+                "y_in": y_in, "z_in": z_in, "_y_tables": yt_h, "_y_center": center}
+
+    @torch.no_grad()
+    def decompress_z(self, z_bytes: bytes, z_shape) -> torch.Tensor:
+        """The hyper-latent: parameter-free prior, decodes in one pass.  Returns z_in [B,M,h4,w4]."""
+        m = self.model
+        B, M, h4, w4 = z_shape
+        dev = next(m.parameters()).device
+        zt = factorized_tables(m.factorized_entropy_model, self.z_lo, self.z_S).cpu().numpy().view(np.uint32)
+        n = B * M * h4 * w4
+        idx = rc_decode(z_bytes, zt, n, np.tile(np.arange(M, dtype=np.int32), n // M))
+        z = torch.from_numpy((idx + self.z_lo).astype(np.float32)).view(B, h4, w4, M).to(dev)
+        return z.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def decode_y_with_tables(y_bytes: bytes, tables: np.ndarray, center: torch.Tensor, y_W: int, shape):
+        """The coder's inverse for y, given the tables / centres the encoder used."""
+        B, M, h, w = shape
+        idx = rc_decode(y_bytes, tables, B * M * h * w)
+        y = torch.from_numpy(idx.astype(np.int32)).view(-1, M) + center.cpu() - int(y_W)
+        return y.view(B, h, w, M).permute(0, 3, 1, 2).float()

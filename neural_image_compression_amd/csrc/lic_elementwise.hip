@@ -596,6 +596,87 @@ LIC_EXPORT int lic_factorized_channel_logits(const float* fe_params, int32_t ch,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Entropy-coder tables (the reference has no coder, D3): 16-bit cumulative frequency
+// tables from the SAME distributions the likelihood kernels evaluate, for the host range coder
+// (lic_codec.h).  A table has S symbols (index i <-> integer value lo + i) and S+1 entries:
+//   cum[i] = floor(F_i * (65536 - S)) + i,   F_0 = 0, F_S = 1, F_i = CDF(lo + i - 0.5) otherwise,
+// so cum[0] = 0, cum[S] = 65536, every symbol keeps frequency >= 1, index 0 carries the whole lower
+// tail and index S-1 the whole upper tail (the coder escapes out-of-window values through them).
+// F is forced non-decreasing (fp32 CDFs can step back by an ulp).
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned cdf_quant(float F, int S) {
+  const float f = fminf(fmaxf(F, 0.0f), 1.0f);
+  unsigned c = (unsigned)floorf(f * (float)(65536 - S));
+  const unsigned cap = (unsigned)(65536 - S);
+  return c > cap ? cap : c;
+}
+// one workgroup per channel: F_i = sigmoid(L_c(lo + i - 0.5))  (EntropyModels.py:171-174)
+__global__ __launch_bounds__(256) void factorized_cdf_tables_kernel(const float* params, int lo, int S,
+                                                                    unsigned* out) {
+  __shared__ float sR[LIC_FE_NPARAM], sT[LIC_FE_NPARAM];
+  extern __shared__ unsigned sq[];
+  const int c = blockIdx.x;
+  fe_load(params + (long)c * LIC_FE_NPARAM, sR, sT);
+  for (int i = threadIdx.x; i <= S; i += 256) {
+    float F = i == 0 ? 0.0f : 1.0f;
+    if (i > 0 && i < S) F = lic_sigmoid(fe_logits(sT, (float)(lo + i) - 0.5f, nullptr));
+    sq[i] = cdf_quant(F, S);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    unsigned run = 0;
+    for (int i = 0; i <= S; ++i) {
+      run = sq[i] > run ? sq[i] : run;
+      out[(long)c * (S + 1) + i] = (i == S ? (unsigned)(65536 - S) : run) + (unsigned)i;
+    }
+  }
+}
+LIC_EXPORT int lic_factorized_cdf_tables(const float* fe_params, int32_t C, int32_t lo, int32_t S, uint32_t* out,
+                                         lic_stream_t stream) {
+  if (!fe_params || !out || C <= 0 || S < 2 || S > 4096) return LIC_ERR_INVALID;
+  hipLaunchKernelGGL(factorized_cdf_tables_kernel, dim3(C), dim3(256), (S + 1) * sizeof(unsigned),
+                     (hipStream_t)stream, fe_params, lo, S, out);
+  return lic_check_launch();
+}
+// one thread per latent element: centre = rint(sum_k w_k mu_k), window [centre - W, centre + W],
+// F(x) = sum_k w_k Phi((x - mu_k) / sigma_k)  (EntropyModels.py:192-233, utils.py:6-8)
+LIC_EXPORT int lic_gmm_cdf_tables(const float* params, int64_t P, int32_t M, int32_t K, int32_t W,
+                                  int32_t* center, uint32_t* out, lic_stream_t stream) {
+  if (!params || !center || !out || P <= 0 || M <= 0 || K < 1 || K > LIC_MAXK || W < 1 || W > 2047)
+    return LIC_ERR_INVALID;
+  const long CH = (long)(K == 1 ? 2 : 3) * K * M;
+  const long T = (long)K * M;
+  const int S = 2 * W + 1;
+  return ew_launch(P * M, stream, [=] __device__(long e) {
+    const long pix = e / M;
+    const int m = (int)(e - pix * M);
+    const float* q = params + pix * CH;
+    float wk[LIC_MAXK], mu[LIC_MAXK], sg[LIC_MAXK];
+    float mean = 0.0f;
+    for (int k = 0; k < K; ++k) {
+      wk[k] = (K == 1) ? 1.0f : q[k * M + m];
+      mu[k] = (K == 1) ? q[m] : q[T + k * M + m];
+      sg[k] = (K == 1) ? q[M + m] : q[2 * T + k * M + m];
+      mean += wk[k] * mu[k];
+    }
+    const int c = (int)rintf(mean);
+    center[e] = c;
+    unsigned* row = out + e * (long)(S + 1);
+    unsigned run = 0;
+    row[0] = 0;
+    for (int i = 1; i < S; ++i) {
+      const float x = (float)(c - W + i) - 0.5f;
+      float F = 0.0f;
+      for (int k = 0; k < K; ++k) F += wk[k] * gauss_cdf((x - mu[k]) / sg[k]);
+      const unsigned v = cdf_quant(F, S);
+      run = v > run ? v : run;
+      row[i] = run + (unsigned)i;
+    }
+    row[S] = 65536u;
+  });
+}
+
+// ---------------------------------------------------------------------------------------------
 // rate-distortion loss (RateDistortionLoss.py:5-49)
 // ---------------------------------------------------------------------------------------------
 #define RD_CHUNKS 64

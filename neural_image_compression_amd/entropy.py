@@ -71,6 +71,11 @@ class FactorizedEntropyBottleneck(EntropyModel):
     def _plists(self):
         return list(self.matrices), list(self.biases), list(self.factors)
 
+    def packed_params(self) -> Tensor:
+        """[C, 43]: matrices | biases | factors per channel, the layout of the lic_factorized_* entries."""
+        Cc = self.channels
+        return torch.cat([q.reshape(Cc, -1) for q in (*self.matrices, *self.biases, *self.factors)], dim=1).contiguous()
+
     def likelihood_and_log(self, inputs: Tensor, bound=None) -> Tuple[Tensor, Tensor]:
         if inputs.dim() < 2:
             raise ValueError("inputs must be at least 2D with channel axis")

@@ -48,9 +48,11 @@ class _HyperpriorContextModel(nn.Module):
         self.decoder.precision = precision
         return self
 
-    def analysis_hyperprior(self, x: torch.Tensor, training: bool = True, noise=None):
+    def analysis_hyperprior(self, x: torch.Tensor, training: bool = True, noise=None, with_packed_params=False):
         """Everything of `forward` except the synthesis transform (Models.py:49-97): the scope the
-        north star quotes its roofline target on.  Returns the out-dict without 'x_hat'."""
+        north star quotes its roofline target on.  Returns the out-dict without 'x_hat'
+        (`with_packed_params`: plus '_act', the activated entropy parameters as the one packed tensor
+        the likelihood / coder-table kernels read)."""
         if x.shape[2] % 64 or x.shape[3] % 64:
             raise RuntimeError("H and W must be multiples of 64 (phi/psi shapes must agree, Models.py:73)")
         y = self.encoder(x)
@@ -81,6 +83,8 @@ class _HyperpriorContextModel(nn.Module):
         out = {'y': y, 'y_in': y_in, 'z': z, 'z_in': z_in, 'p_z': p_z, 'logp_z': logp_z,
                'p_y': p_y, 'logp_y': logp_y, 'training': training}
         out.update(params)
+        if with_packed_params:
+            out['_act'] = act
         return out
 
     def forward(self, x: torch.Tensor, training: bool = True, noise=None):
