@@ -37,6 +37,14 @@ int lic_rc_encode(const uint32_t* tables, const int32_t* table_of, int32_t S, co
 int lic_rc_decode(const uint8_t* in, size_t nbytes, const uint32_t* tables, const int32_t* table_of, int32_t S,
                   int64_t n, int32_t* idx_out);
 
+/* Streaming decoder: the tables of later symbols may depend on symbols already decoded (the
+ * raster-order context model).  `in` must stay valid until lic_rc_decoder_free. */
+typedef struct lic_rc_decoder lic_rc_decoder;
+lic_rc_decoder* lic_rc_decoder_new(const uint8_t* in, size_t nbytes);
+int lic_rc_decoder_next(lic_rc_decoder* dec, const uint32_t* tables, const int32_t* table_of, int32_t S, int64_t n,
+                        int32_t* idx_out);
+void lic_rc_decoder_free(lic_rc_decoder* dec);
+
 /* -sum log2(freq/65536) of the coded symbols (escape bits included): the ideal size of the stream
  * for these tables, to compare with 8 * nbytes */
 double lic_rc_ideal_bits(const uint32_t* tables, const int32_t* table_of, int32_t S, const int32_t* idx,

@@ -170,3 +170,137 @@ class LatentCodec:
         idx = rc_decode(y_bytes, tables, B * M * h * w)
         y = torch.from_numpy(idx.astype(np.int32)).view(-1, M) + center.cpu() - int(y_W)
         return y.view(B, h, w, M).permute(0, 3, 1, 2).float()
+
+
+# ---------------------------------------------------------------------------------------------
+# Full bitstream with the autoregressive context: the serial step
+# ---------------------------------------------------------------------------------------------
+class _StreamDecoder:
+    """lic_rc_decoder_* wrapper (one per image stream)."""
+
+    def __init__(self, data: bytes):
+        lib = _codec()
+        lib.lic_rc_decoder_new.restype = C.c_void_p
+        lib.lic_rc_decoder_new.argtypes = [C.POINTER(C.c_uint8), C.c_size_t]
+        lib.lic_rc_decoder_next.restype = C.c_int
+        lib.lic_rc_decoder_next.argtypes = [C.c_void_p, C.POINTER(C.c_uint32), C.POINTER(C.c_int32), C.c_int32,
+                                            C.c_int64, C.POINTER(C.c_int32)]
+        lib.lic_rc_decoder_free.argtypes = [C.c_void_p]
+        self._buf = np.frombuffer(data, np.uint8).copy()
+        self._h = lib.lic_rc_decoder_new(_p(self._buf, C.c_uint8), self._buf.size)
+        if not self._h:
+            raise CodecError("lic_rc_decoder_new failed")
+
+    def next(self, tables: np.ndarray, n: int) -> np.ndarray:
+        tables = np.ascontiguousarray(tables, np.uint32)
+        out = np.empty(n, np.int32)
+        rc = _codec().lic_rc_decoder_next(self._h, _p(tables, C.c_uint32), None, tables.shape[-1] - 1, n,
+                                          _p(out, C.c_int32))
+        if rc != 0:
+            raise CodecError(f"lic_rc_decoder_next failed with status {rc}")
+        return out
+
+    def close(self):
+        if self._h:
+            _codec().lic_rc_decoder_free(self._h)
+            self._h = None
+
+    def __del__(self):
+        self.close()
+
+
+class ContextCodec:
+    """compress(x) -> byte strings, decompress(strings) -> x_hat, through the model's masked-conv
+    context (ContextModels.py:3-36): the parameters of pixel (i, j) of y depend on the already decoded
+    pixels above / left of it, so decoding walks the latent grid in raster order -- h*w dependent
+    steps of {12-tap context GEMM -> entropy-parameter MLP -> table kernel} on the GPU and M symbols
+    per image on the host coder.
+
+    Encoder and decoder must build BIT-IDENTICAL tables, so both evaluate the context as the same
+    per-pixel GEMM over the 12 live taps ([N, 12M, 1, 1] "images": the kernels' results for one row do
+    not depend on the batch it sits in, and their split-K choice depends on per-image geometry only --
+    the property tests/test_gpu_fullsize.py pins); the encoder simply has all N = B*h*w pixels at
+    once.  One y stream per image (symbol order i, j, m) + one z stream for the batch."""
+
+    def __init__(self, model, z_lo: int = -64, z_S: int = 129, y_W: int = 32):
+        self.model, self.z_lo, self.z_S, self.y_W = model, int(z_lo), int(z_S), int(y_W)
+        mc = model.context_model.masked
+        k = mc.kernel_size[0]
+        self.taps = [(r, s) for r in range(k) for s in range(k) if (mc._tap_mask >> (r * k + s)) & 1]
+        self.k, self.pad = k, mc.padding[0]
+
+    def _ctx_weight(self):
+        mc = self.model.context_model.masked
+        w = (mc.weight * mc.mask).detach()                                     # [2M, M, k, k]
+        cols = [w[:, :, r, s] for (r, s) in self.taps]                         # each [2M, M]
+        return torch.cat(cols, dim=1).reshape(w.shape[0], -1, 1, 1).contiguous(), mc.bias.detach()
+
+    def _params_at(self, windows: torch.Tensor, psi_px: torch.Tensor, wg, bg):
+        """windows [N, 12M, 1, 1], psi_px [N, 2M, 1, 1] -> (center [N, M], tables [N*M, S+1] on the host)"""
+        m = self.model
+        phi = F_.conv2d(windows, wg, bg, 1, 0)
+        act = m.entropy_parameters.packed(torch.cat([phi, psi_px], dim=1))
+        center, tables = gmm_tables(act, m.M, m.K, self.y_W)
+        return center, tables
+
+    def _windows_all(self, y_hat: torch.Tensor) -> torch.Tensor:
+        """[B, M, h, w] -> [B*h*w, 12M, 1, 1]: the live taps of every pixel (zeros outside the image)"""
+        B, M, h, w = y_hat.shape
+        p = self.pad
+        yp = torch.nn.functional.pad(y_hat, (p, p, p, p))
+        cols = [yp[:, :, r:r + h, s:s + w] for (r, s) in self.taps]              # each [B, M, h, w]
+        win = torch.cat(cols, dim=1)                                              # [B, 12M, h, w]
+        return win.permute(0, 2, 3, 1).reshape(B * h * w, -1, 1, 1).contiguous()
+
+    @torch.no_grad()
+    def compress(self, x: torch.Tensor) -> Dict:
+        m = self.model
+        out = m.analysis_hyperprior(x, training=False)
+        y_in, z_in = out["y_in"].contiguous(), out["z_in"]
+        B, M, h, w = y_in.shape
+        zt = factorized_tables(m.factorized_entropy_model, self.z_lo, self.z_S).cpu().numpy().view(np.uint32)
+        z_idx = (z_in.permute(0, 2, 3, 1).contiguous().round().to(torch.int32) - self.z_lo).cpu().numpy().ravel()
+        z_bytes = rc_encode(zt, z_idx, np.tile(np.arange(M, dtype=np.int32), z_idx.size // M))
+        psi = m.hyper_decoder(z_in)
+        wg, bg = self._ctx_weight()
+        psi_px = psi.permute(0, 2, 3, 1).reshape(B * h * w, -1, 1, 1).contiguous()
+        center, tables = self._params_at(self._windows_all(y_in), psi_px, wg, bg)
+        y_sym = y_in.permute(0, 2, 3, 1).reshape(B * h * w, M).round().to(torch.int32)
+        idx = (y_sym - center + self.y_W).cpu().numpy().reshape(B, h * w * M)
+        tabs = tables.cpu().numpy().view(np.uint32).reshape(B, h * w * M, -1)
+        y_streams = [rc_encode(tabs[b], idx[b]) for b in range(B)]
+        npix = x.shape[0] * x.shape[2] * x.shape[3]
+        coded = 8.0 * (len(z_bytes) + sum(len(s) for s in y_streams)) / npix
+        est = float(-(out["logp_y"].double().sum() + out["logp_z"].double().sum()) / np.log(2.0) / npix)
+        return {"strings": {"y": y_streams, "z": z_bytes}, "shape": (B, M, h, w), "z_shape": tuple(z_in.shape),
+                "bpp_coded": coded, "bpp_est": est, "y_in": y_in, "z_in": z_in}
+
+    @torch.no_grad()
+    def decompress(self, strings: Dict, shape, z_shape) -> Dict:
+        m = self.model
+        B, M, h, w = shape
+        dev = next(m.parameters()).device
+        z_hat = LatentCodec(m, self.z_lo, self.z_S, self.y_W).decompress_z(strings["z"], z_shape)
+        z_hat = z_hat.contiguous(memory_format=torch.channels_last)
+        psi = m.hyper_decoder(z_hat)
+        wg, bg = self._ctx_weight()
+        p = self.pad
+        ypad = torch.zeros((B, M, h + 2 * p, w + 2 * p), device=dev, dtype=torch.float32)
+        decs = [_StreamDecoder(s) for s in strings["y"]]
+        try:
+            for i in range(h):
+                for j in range(w):
+                    cols = [ypad[:, :, i + r, j + s] for (r, s) in self.taps]        # each [B, M]
+                    win = torch.cat(cols, dim=1).reshape(B, -1, 1, 1).contiguous()
+                    psi_px = psi[:, :, i, j].reshape(B, -1, 1, 1).contiguous()
+                    center, tables = self._params_at(win, psi_px, wg, bg)
+                    tabs = tables.cpu().numpy().view(np.uint32).reshape(B, M, -1)
+                    c = center.cpu().numpy()
+                    vals = np.stack([decs[b].next(tabs[b], M) + c[b] - self.y_W for b in range(B)])
+                    ypad[:, :, i + p, j + p] = torch.from_numpy(vals.astype(np.float32)).to(dev)
+        finally:
+            for d in decs:
+                d.close()
+        y_hat = ypad[:, :, p:p + h, p:p + w].contiguous(memory_format=torch.channels_last)
+        x_hat = m.decoder(y_hat)
+        return {"x_hat": x_hat, "y_hat": y_hat, "z_hat": z_hat}

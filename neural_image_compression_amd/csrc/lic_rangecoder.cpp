@@ -2,6 +2,7 @@
 // with byte-wise renormalisation (the LZMA scheme: 64-bit `low`, a cached byte and a run of 0xFF
 // bytes absorb carries), 16-bit cumulative frequencies, Elias-gamma escapes in equiprobable bits.
 #include <math.h>
+#include <new>
 #include <stddef.h>
 #include <stdint.h>
 
@@ -137,10 +138,8 @@ LIC_CODEC_EXPORT int lic_rc_encode(const uint32_t* tables, const int32_t* table_
   return LIC_CODEC_OK;
 }
 
-LIC_CODEC_EXPORT int lic_rc_decode(const uint8_t* in, size_t nbytes, const uint32_t* tables, const int32_t* table_of,
-                                   int32_t S, int64_t n, int32_t* idx_out) {
-  if (!in || !tables || !idx_out || S < 2 || n < 0) return LIC_CODEC_ERR_INVALID;
-  Decoder d(in, nbytes);
+static int decode_some(Decoder& d, const uint32_t* tables, const int32_t* table_of, int32_t S, int64_t n,
+                       int32_t* idx_out) {
   for (int64_t i = 0; i < n; ++i) {
     const uint32_t* t = tables + (size_t)(table_of ? table_of[i] : i) * (size_t)(S + 1);
     if (!table_ok(t, S)) return LIC_CODEC_ERR_INVALID;
@@ -166,6 +165,29 @@ LIC_CODEC_EXPORT int lic_rc_decode(const uint8_t* in, size_t nbytes, const uint3
   }
   return LIC_CODEC_OK;
 }
+
+LIC_CODEC_EXPORT int lic_rc_decode(const uint8_t* in, size_t nbytes, const uint32_t* tables, const int32_t* table_of,
+                                   int32_t S, int64_t n, int32_t* idx_out) {
+  if (!in || !tables || !idx_out || S < 2 || n < 0) return LIC_CODEC_ERR_INVALID;
+  Decoder d(in, nbytes);
+  return decode_some(d, tables, table_of, S, n, idx_out);
+}
+
+// streaming form: the tables of later symbols may depend on earlier decoded ones (context models)
+struct lic_rc_decoder {
+  Decoder d;
+  lic_rc_decoder(const uint8_t* in, size_t n) : d(in, n) {}
+};
+LIC_CODEC_EXPORT lic_rc_decoder* lic_rc_decoder_new(const uint8_t* in, size_t nbytes) {
+  if (!in) return nullptr;
+  return new (std::nothrow) lic_rc_decoder(in, nbytes);
+}
+LIC_CODEC_EXPORT int lic_rc_decoder_next(lic_rc_decoder* dec, const uint32_t* tables, const int32_t* table_of,
+                                         int32_t S, int64_t n, int32_t* idx_out) {
+  if (!dec || !tables || !idx_out || S < 2 || n < 0) return LIC_CODEC_ERR_INVALID;
+  return decode_some(dec->d, tables, table_of, S, n, idx_out);
+}
+LIC_CODEC_EXPORT void lic_rc_decoder_free(lic_rc_decoder* dec) { delete dec; }
 
 LIC_CODEC_EXPORT double lic_rc_ideal_bits(const uint32_t* tables, const int32_t* table_of, int32_t S,
                                           const int32_t* idx, int64_t n) {

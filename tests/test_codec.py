@@ -154,3 +154,31 @@ def test_coded_bpp_matches_estimate_and_round_trips(codec, K):
     tot_c = res["bpp_coded_y"] + res["bpp_coded_z"]
     tot_e = res["bpp_est_y"] + res["bpp_est_z"]
     assert abs(tot_c - tot_e) <= 0.02 * tot_e + 128.0 / npix, (tot_c, tot_e)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,B,H,W", [(1, 2, 64, 128), (3, 1, 128, 64)])
+def test_context_codec_full_round_trip(codec, K, B, H, W):
+    """compress -> bytes -> decompress through the raster-order masked-conv context: the decoded
+    latents equal the encoder's exactly, x_hat equals the model's eval output, coded ~ estimated."""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import neural_image_compression_amd as nic
+    import golden_recipe as R
+    M = 32
+    model = nic.JointAutoregressiveHierarchical(M, K)
+    st = R.make_state([(k, tuple(v.shape)) for k, v in model.state_dict().items()], 51)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
+    model = model.cuda().eval()
+    x = torch.from_numpy(R.make_image(B, H, W, 52)).cuda().contiguous(memory_format=torch.channels_last)
+    cc = codec.ContextCodec(model, z_lo=-32, z_S=65, y_W=24)
+    enc = cc.compress(x)
+    assert len(enc["strings"]["y"]) == B
+    dec = cc.decompress(enc["strings"], enc["shape"], enc["z_shape"])
+    assert torch.equal(dec["z_hat"], enc["z_in"])
+    assert torch.equal(dec["y_hat"], enc["y_in"]), "decoder tables diverged from the encoder's"
+    with torch.no_grad():
+        ref = model(x, training=False)
+    assert torch.equal(dec["x_hat"], ref["x_hat"])
+    npix = B * H * W
+    assert abs(enc["bpp_coded"] - enc["bpp_est"]) <= 0.02 * enc["bpp_est"] + (64.0 * (B + 1)) / npix
