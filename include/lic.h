@@ -296,6 +296,20 @@ int lic_msssim(const float* x, const float* y, int32_t B, int32_t C, int32_t H, 
                int64_t sc, int64_t sh, int64_t sw, float data_range, float* out, float* level_out,
                void* workspace, size_t workspace_bytes, lic_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * SURVEY 8(f).3 -- input pipeline and logging statistics.
+ *   lic_u8_to_f32: out[i] = float(in[i]) / 255 (true division: bit-identical to torchvision
+ *     ToTensor(), Dataloader.py:7-9) for uint8 NHWC shards; `in` 4-byte, `out` 16-byte aligned.
+ *   lic_tensor_stats: stats[6] = count, sum, sum of squares, min, max, NaN count (fp64) and hist[nbins]
+ *     (uint64) over [lo, hi] with outliers clamped into the edge bins -- the summary the reference's
+ *     logging (Trainer.py:167-217: add_histogram / mean of whole latent tensors) needs, without the
+ *     full-tensor D2H copy.  Reproducible (integer atomics + fixed-order fp64 reduction).
+ * ------------------------------------------------------------------------------------------ */
+int lic_u8_to_f32(const uint8_t* in, float* out, int64_t n, lic_stream_t stream);
+size_t lic_tensor_stats_workspace_bytes(void);
+int lic_tensor_stats(const float* x, int64_t n, int32_t nbins, float lo, float hi, double* stats,
+                     uint64_t* hist, void* workspace, size_t workspace_bytes, lic_stream_t stream);
+
 int lic_version(void);        /* LIC_ABI_VERSION */
 int lic_last_hip_error(void); /* hipError_t of the most recent failed launch on this thread */
 const char* lic_arch(void);   /* "gfx950" */

@@ -92,6 +92,9 @@ SIGNATURES = {
     "lic_msssim_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "lic_msssim": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i64, _i64, _i64, _i64, _f32, _vp, _vp, _vp, _sz,
                              _vp]),
+    "lic_u8_to_f32": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "lic_tensor_stats_workspace_bytes": (_sz, []),
+    "lic_tensor_stats": (C.c_int, [_vp, _i64, _i32, _f32, _f32, _vp, _vp, _vp, _sz, _vp]),
     "lic_version": (C.c_int, []),
     "lic_last_hip_error": (C.c_int, []),
     "lic_arch": (C.c_char_p, []),

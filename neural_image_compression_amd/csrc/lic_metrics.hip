@@ -255,3 +255,109 @@ LIC_EXPORT int lic_msssim(const float* x, const float* y, int32_t B, int32_t C, 
   hipLaunchKernelGGL(msssim_combine_kernel, dim3((BC + 63) / 64), dim3(64), 0, s, (const float*)level_out, BC, out);
   return lic_check_launch();
 }
+
+// ------------------------------------------------------------------------------------------------
+// SURVEY 8(f).3 -- input pipeline and logging statistics on the device.
+// ------------------------------------------------------------------------------------------------
+// uint8 NHWC pixels -> fp32 in [0,1]: out = float(v) / 255 (a true division: bit-identical to
+// torchvision's ToTensor(), Dataloader.py:7-9).  n % 4 == 0 takes the 4-pixel path.
+__global__ __launch_bounds__(256) void u8_to_f32_kernel(const uint8_t* in, float* out, long n) {
+  const long n4 = n >> 2;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const uchar4 v = reinterpret_cast<const uchar4*>(in)[i];
+    f32x4 o = {(float)v.x / 255.0f, (float)v.y / 255.0f, (float)v.z / 255.0f, (float)v.w / 255.0f};
+    reinterpret_cast<f32x4*>(out)[i] = o;
+  }
+  for (long i = (n4 << 2) + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    out[i] = (float)in[i] / 255.0f;
+}
+LIC_EXPORT int lic_u8_to_f32(const uint8_t* in, float* out, int64_t n, lic_stream_t stream) {
+  if (!in || !out || n < 0) return LIC_ERR_INVALID;
+  if (n == 0) return LIC_OK;
+  if ((reinterpret_cast<uintptr_t>(in) & 3) || (reinterpret_cast<uintptr_t>(out) & 15)) return LIC_ERR_INVALID;
+  hipLaunchKernelGGL(u8_to_f32_kernel, dim3(ew_grid(n / 4 + 1, 256)), dim3(256), 0, (hipStream_t)stream, in, out,
+                     (long)n);
+  return lic_check_launch();
+}
+
+// Summary of a tensor for logging (what Trainer.py:167-217 ships to the host as whole tensors):
+// stats[0..4] = count, sum, sum of squares, min, max (fp64) and a fixed-range histogram of `nbins`
+// equal bins over [lo, hi] (values outside are clamped into the edge bins; NaNs are skipped and
+// counted in stats[5]).  Integer bin counts via atomics (order-independent), fp64 sums via per-block
+// partials reduced in fixed order => reproducible.
+#define ST_BLOCKS 256
+__global__ __launch_bounds__(256) void tensor_stats_kernel(const float* x, long n, int nbins, float lo, float inv_w,
+                                                           double* partial, unsigned long long* hist) {
+  extern __shared__ unsigned sh_hist[];
+  __shared__ double red[6][4];
+  for (int i = threadIdx.x; i < nbins; i += 256) sh_hist[i] = 0;
+  __syncthreads();
+  double s = 0.0, ss = 0.0, cnt = 0.0, nan = 0.0;
+  double mn = 1e300, mx = -1e300;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float v = x[i];
+    if (v != v) {
+      nan += 1.0;
+      continue;
+    }
+    s += (double)v;
+    ss += (double)v * (double)v;
+    cnt += 1.0;
+    mn = (double)v < mn ? (double)v : mn;
+    mx = (double)v > mx ? (double)v : mx;
+    int b = (int)floorf((v - lo) * inv_w);
+    b = b < 0 ? 0 : (b >= nbins ? nbins - 1 : b);
+    atomicAdd(&sh_hist[b], 1u);
+  }
+  double vals[6] = {cnt, s, ss, mn, mx, nan};
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    double v = vals[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const double o = __shfl_down(v, off, 64);
+      v = (k == 3) ? (o < v ? o : v) : (k == 4 ? (o > v ? o : v) : v + o);
+    }
+    if ((threadIdx.x & 63) == 0) red[k][threadIdx.x >> 6] = v;
+  }
+  __syncthreads();
+  if (threadIdx.x < 6) {
+    const int k = threadIdx.x;
+    double v = red[k][0];
+    for (int w = 1; w < 4; ++w) v = (k == 3) ? (red[k][w] < v ? red[k][w] : v) : (k == 4 ? (red[k][w] > v ? red[k][w] : v) : v + red[k][w]);
+    partial[(long)blockIdx.x * 6 + k] = v;
+  }
+  for (int i = threadIdx.x; i < nbins; i += 256)
+    if (sh_hist[i]) atomicAdd(&hist[i], (unsigned long long)sh_hist[i]);
+}
+__global__ __launch_bounds__(64) void tensor_stats_finish_kernel(const double* partial, int nblocks, double* stats) {
+  const int k = threadIdx.x;
+  if (k >= 6) return;
+  double v = partial[k];
+  for (int b = 1; b < nblocks; ++b) {
+    const double o = partial[(long)b * 6 + k];
+    v = (k == 3) ? (o < v ? o : v) : (k == 4 ? (o > v ? o : v) : v + o);
+  }
+  stats[k] = v;
+}
+LIC_EXPORT size_t lic_tensor_stats_workspace_bytes(void) { return (size_t)ST_BLOCKS * 6 * sizeof(double); }
+LIC_EXPORT int lic_tensor_stats(const float* x, int64_t n, int32_t nbins, float lo, float hi, double* stats,
+                                uint64_t* hist, void* workspace, size_t workspace_bytes, lic_stream_t stream) {
+  if (!x || !stats || !hist || !workspace || n <= 0 || nbins < 1 || nbins > 4096 || !(hi > lo)) return LIC_ERR_INVALID;
+  if (workspace_bytes < lic_tensor_stats_workspace_bytes()) return LIC_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  int nb = (int)cdiv64(n, 256 * 8);
+  if (nb > ST_BLOCKS) nb = ST_BLOCKS;
+  if (nb < 1) nb = 1;
+  hipError_t e = hipMemsetAsync(hist, 0, (size_t)nbins * sizeof(uint64_t), s);
+  if (e != hipSuccess) {
+    g_lic_last_hip_error = (int)e;
+    return LIC_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(tensor_stats_kernel, dim3(nb), dim3(256), nbins * sizeof(unsigned), s, x, (long)n, nbins, lo,
+                     (float)nbins / (hi - lo), (double*)workspace, (unsigned long long*)hist);
+  int rc = lic_check_launch();
+  if (rc != LIC_OK) return rc;
+  hipLaunchKernelGGL(tensor_stats_finish_kernel, dim3(1), dim3(64), 0, s, (const double*)workspace, nb, stats);
+  return lic_check_launch();
+}

@@ -7,9 +7,12 @@ modes 'plateau' / 'cosine' (:32-40, :94-99), interval defaults max_steps/200, /2
 checkpoint dict keys model/optimizer/step/scheduler and `max_steps += step` on resume (:52-71),
 scalar tags `losses/<key>` for every float of the loss dict (:140-143) and the three validation
 tags (:162-164, including the reference's "validation_pnsr" spelling).
-Not reproduced (observability only): TensorBoard histogram / image / figure
-logging (:167-345).  Scalars go to a TensorBoard SummaryWriter when tensorboard is installed,
-otherwise to <log_dir>/scalars.jsonl.
+The reference's histogram logging (:167-217) ships whole latent tensors to the host every
+`log_interval`; here `_log_histograms` / `_log_channel_activity` / `_log_entropy_params` emit the
+same tags from device-side summaries (`data.tensor_stats` -> `lic_tensor_stats`: count, mean, std,
+min, max and a 64-bin histogram; 6 doubles + 64 counters cross PCIe per tag).  Image / figure logging
+(:219-345) is not reproduced.  Scalars go to a TensorBoard SummaryWriter when tensorboard is
+installed, otherwise to <log_dir>/scalars.jsonl (summaries as JSON objects).
 """
 from __future__ import annotations
 
@@ -31,6 +34,9 @@ class _JsonlWriter:
 
     def add_scalar(self, tag, value, step):
         self.f.write(json.dumps({"tag": tag, "value": float(value), "step": int(step)}) + "\n")
+
+    def add_summary(self, tag, summary, step):
+        self.f.write(json.dumps({"tag": tag, "summary": summary, "step": int(step)}) + "\n")
 
     def close(self):
         self.f.close()
@@ -62,6 +68,7 @@ class Trainer:
         self.step = 0
         self.train_iter = iter(train_loader)
         self.log_interval = log_interval if log_interval else int(self.max_steps / 200)
+        self.log_statistics = True  # latent / likelihood summaries every log_interval (Trainer.py:88-92)
         self.img_interval = img_interval if img_interval else int(self.max_steps / 25)
         self.val_interval = val_interval if val_interval else int(self.max_steps / 200)
         if scheduler == 'plateau':
@@ -127,8 +134,14 @@ class Trainer:
     def train(self):
         while self.step < self.max_steps:
             imgs = self._next_batch()
-            _, results = self.train_step(imgs)
+            model_out, results = self.train_step(imgs)
             self._log_scalars(results)
+            if self.writer is not None and self.log_interval and self.step % self.log_interval == 0 and \
+                    self.log_statistics and self._has_device_outputs(model_out):
+                self._log_histograms(model_out)
+                self._log_channel_activity(model_out, 'y')
+                self._log_channel_activity(model_out, 'z')
+                self._log_entropy_params(model_out)
             if self.val_loader is not None and self.val_interval and self.step % self.val_interval == 0:
                 val_loss = self._validate()
                 if self.use_plateau:
@@ -156,6 +169,53 @@ class Trainer:
         for k, v in results.items():
             if isinstance(v, (float, int)):
                 self.writer.add_scalar(f"losses/{k}", v, self.step)
+
+    # ---- Trainer.py:167-217 from device-side summaries --------------------------------------
+    @staticmethod
+    def _has_device_outputs(model_out):
+        keys = ("y", "y_in", "z", "z_in", "logp_y", "logp_z", "p_y", "p_z")
+        return all(k in model_out and torch.is_tensor(model_out[k]) and model_out[k].is_cuda for k in keys)
+
+    def _summary(self, tag, t):
+        from .data import tensor_stats
+        st = tensor_stats(t)
+        if hasattr(self.writer, "add_summary"):
+            self.writer.add_summary(tag, st, self.step)
+        else:  # a TensorBoard writer: the scalar moments
+            for k in ("mean", "std", "min", "max"):
+                self.writer.add_scalar(f"{tag}/{k}", st[k], self.step)
+        return st
+
+    def _log_histograms(self, model_out):
+        ln2 = 0.6931471805599453
+        for tag, key in (("latents/y", "y"), ("latents/y_hat", "y_in"), ("latents/z", "z"), ("latents/z_hat", "z_in"),
+                         ("probability/logp_y", "logp_y"), ("probability/logp_z", "logp_z"),
+                         ("probability/p_y", "p_y"), ("probability/p_z", "p_z")):
+            st = self._summary(tag, model_out[key])
+            if key in ("logp_y", "logp_z", "p_y", "p_z"):
+                self.writer.add_scalar(f"probability/{key}_mean", st["mean"], self.step)
+            if key in ("logp_y", "logp_z"):
+                self.writer.add_scalar(f"entropy/entropy_{key[-1]}_mean", -st["mean"] / ln2, self.step)
+        for n in ("y", "z"):
+            logp = model_out["logp_" + n].detach()
+            self._summary(f"entropy/{n}", -logp / ln2)
+            self._summary(f"entropy/{n}_per_component", -logp.sum(dim=(2, 3)) / ln2)
+
+    def _log_channel_activity(self, model_out, tensor_name='y'):
+        logp = model_out['logp_' + tensor_name].detach()
+        avg_bits_per_c = (-logp / 0.6931471805599453).mean(dim=(0, 2, 3))
+        self.writer.add_scalar(f"activity/{tensor_name}_dead_channels_by_entropy",
+                               float((avg_bits_per_c < 1e-4).float().sum()), self.step)
+
+    def _log_entropy_params(self, model_out):
+        if 'mu' in model_out and 'sigma' in model_out:
+            self._summary("entropy_params/mu", model_out['mu'])
+            self._summary("entropy_params/sigma", model_out['sigma'])
+        if 'weights' in model_out:
+            for k in ("weights", "mus", "sigmas"):
+                self._summary(f"entropy_params/{k}", model_out[k])
+            used = (model_out['weights'].detach() > 1e-4).float().sum(dim=1).mean()
+            self.writer.add_scalar("entropy_params/used_components_mean", float(used), self.step)
 
     def _validate(self):
         self.model.eval()
