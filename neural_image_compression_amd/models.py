@@ -48,26 +48,31 @@ class _HyperpriorContextModel(nn.Module):
         self.decoder.precision = precision
         return self
 
-    def analysis_hyperprior(self, x: torch.Tensor, training: bool = True, noise=None, with_packed_params=False):
+    def analysis_hyperprior(self, x: torch.Tensor, training: bool = True, noise=None, with_packed_params=False,
+                            _fork=None):
         """Everything of `forward` except the synthesis transform (Models.py:49-97): the scope the
         north star quotes its roofline target on.  Returns the out-dict without 'x_hat'
         (`with_packed_params`: plus '_act', the activated entropy parameters as the one packed tensor
-        the likelihood / coder-table kernels read)."""
+        the likelihood / coder-table kernels read).  `_fork(y_in)` is called as soon as y_in exists."""
         if x.shape[2] % 64 or x.shape[3] % 64:
             raise RuntimeError("H and W must be multiples of 64 (phi/psi shapes must agree, Models.py:73)")
         y = self.encoder(x)
-        z = self.hyper_encoder(y)
         if training:
             if noise is None:
-                uz = torch.rand_like(z)
+                # the reference draws rand_like(z) then rand_like(y) (Models.py:57-58); z's shape is known
+                # before z is, and drawing both here lets the decoder branch start right after the encoder
+                zshape = (y.shape[0], y.shape[1], (y.shape[2] + 3) // 4, (y.shape[3] + 3) // 4)
+                uz = torch.rand(zshape, device=y.device, dtype=y.dtype)
                 uy = torch.rand_like(y)
             else:
                 uz, uy = noise
-            z_in = F_.quantize(z, uz, True)
             y_in = F_.quantize(y, uy, True)
         else:
-            z_in = F_.quantize(z, None, False)
             y_in = F_.quantize(y, None, False)
+        if _fork is not None:
+            _fork(y_in)
+        z = self.hyper_encoder(y)
+        z_in = F_.quantize(z, uz, True) if training else F_.quantize(z, None, False)
         psi = self.hyper_decoder(z_in)
         phi = self.context_model(y_in)
         combined = torch.cat([phi, psi], dim=1)  # layout copy only (phi first)
@@ -87,12 +92,34 @@ class _HyperpriorContextModel(nn.Module):
             out['_act'] = act
         return out
 
+    # The synthesis transform depends only on y_in; the hyper / context / likelihood branch only on
+    # (y, y_in): independent until rd_loss.  With `overlap_branches` the decoder runs on a second HIP
+    # stream beside the latent-side branch (many small launches that cannot fill 256 CUs by
+    # themselves), in forward and -- autograd replays each op on its forward stream -- in backward.
+    overlap_branches = True
+
     def forward(self, x: torch.Tensor, training: bool = True, noise=None):
         """`noise` (test hook, not in the reference): (u_z, u_y) uniform [0,1) tensors used instead
         of torch.rand_like, in the reference's draw order (z first, Models.py:57-58)."""
-        out = self.analysis_hyperprior(x, training, noise)
-        x_hat = self.decoder(out['y_in'])
-        return {'x_hat': x_hat, **out}
+        if not (self.overlap_branches and x.is_cuda):
+            out = self.analysis_hyperprior(x, training, noise)
+            return {'x_hat': self.decoder(out['y_in']), **out}
+        main = torch.cuda.current_stream()
+        if getattr(self, "_side_stream", None) is None:
+            self._side_stream = torch.cuda.Stream()
+        side = self._side_stream
+        box = {}
+
+        def fork(y_in):
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                box['x_hat'] = self.decoder(y_in)
+            y_in.record_stream(side)
+
+        out = self.analysis_hyperprior(x, training, noise, _fork=fork)
+        main.wait_stream(side)
+        box['x_hat'].record_stream(main)
+        return {'x_hat': box['x_hat'], **out}
 
 
 class JointAutoregressiveHierarchical(_HyperpriorContextModel):

@@ -43,6 +43,7 @@ class GradientAllReducer:
         self._flat: List[Optional[torch.Tensor]] = [None] * len(self.buckets)
         self._pending = [0] * len(self.buckets)
         self._work = [None] * len(self.buckets)
+        self._events = [[] for _ in self.buckets]  # one per gradient: backward may run on several streams
         self._hooks = []
         if self.world > 1 and overlap:
             for i, p in enumerate(self.params):
@@ -53,10 +54,17 @@ class GradientAllReducer:
         for b, idxs in enumerate(self.buckets):
             self._pending[b] = len(idxs)
             self._work[b] = None
+            self._events[b] = []
 
     def _make_hook(self, i):
         def hook(_p):
             b = self._bucket_of[i]
+            if _p.grad is not None and _p.grad.is_cuda:
+                # the model overlaps its decoder and latent branches on two HIP streams, so a bucket's
+                # gradients can come from different streams: fence each one where it was produced
+                ev = torch.cuda.Event()
+                ev.record()
+                self._events[b].append(ev)
             self._pending[b] -= 1
             if self._pending[b] == 0:
                 self._launch(b)
@@ -64,6 +72,8 @@ class GradientAllReducer:
 
     def _launch(self, b):
         ps = [self.params[i] for i in self.buckets[b]]
+        for ev in self._events[b]:
+            torch.cuda.current_stream().wait_event(ev)
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in ps]
         flat = torch.cat([g.reshape(-1) for g in grads])
         self._flat[b] = flat
