@@ -21,7 +21,8 @@ LIKELIHOOD_BOUND = 1e-9
 
 # bench.py sets this to a list to collect (kernel, flops, activation_bytes, start_evt, end_evt) for
 # every MFMA launch; HIP events are recorded on the stream the kernels are launched on.
-PROFILE = None
+PROFILE = None           # list -> every MFMA launch appends (kernel name, FLOP, bytes, start event, end event)
+PROFILE_MIN_FLOP = 0.0   # launches below this many algorithmic FLOP are not bracketed (event overhead)
 
 
 # ------------------------------------------------------------------------------------------
@@ -114,7 +115,7 @@ def _igemm(inp, w_packed, out, *, B, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, 
         if nbytes:
             ws = torch.empty(nbytes // 4, device=inp.device, dtype=torch.float32)
             d.workspace, d.workspace_bytes = _ptr(ws), nbytes
-    if PROFILE is None:
+    if PROFILE is None or 2.0 * B * Ho * Wo * Cout * Cin * kh * kw < PROFILE_MIN_FLOP:
         L.check(lib.lic_igemm(C.byref(d), _stream()), "lic_igemm")
         return
     bm, bn, macs = C.c_int32(0), C.c_int32(0), C.c_int64(0)
@@ -145,7 +146,7 @@ def _wgrad(p, g, dst, *, B, Hs, Ws, Cp, Hl, Wl, Cg, kh, kw, stride, pad, g_is_ro
     lib = L.load()
     nbytes = lib.lic_wgrad_workspace_bytes(C.byref(d))
     ws = torch.empty((max(nbytes, 4) + 3) // 4, device=p.device, dtype=torch.float32)
-    if PROFILE is None:
+    if PROFILE is None or 2.0 * B * Hs * Ws * kh * kw * Cp * Cg < PROFILE_MIN_FLOP:
         L.check(lib.lic_wgrad(C.byref(d), _ptr(ws), nbytes, _stream()), "lic_wgrad")
         return
     nm = C.create_string_buffer(96)

@@ -63,7 +63,7 @@ def _igemm_bf16(inp, w_packed, out, *, B, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, str
     d.transposed, d.prologue, d.epilogue = int(transposed), prologue, epilogue
     d.tap_mask, d.slope = 0, 0.01
     from . import functional as F_
-    if F_.PROFILE is None:
+    if F_.PROFILE is None or 2.0 * B * Ho * Wo * Cout * Cin * kh * kw < F_.PROFILE_MIN_FLOP:
         L.check(L.load().lic_igemm_bf16(C.byref(d), int(out.dtype == torch.float32), _stream()), "lic_igemm_bf16")
         return
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -91,7 +91,7 @@ def _wgrad_bf16(p, g, dst, *, B, Hs, Ws, Cp, Hl, Wl, Cg, kh, kw, stride, pad, g_
     nbytes = lib.lic_wgrad_bf16_workspace_bytes(C.byref(d))
     ws = torch.empty((max(nbytes, 4) + 3) // 4, device=p.device, dtype=torch.float32)
     from . import functional as F_
-    if F_.PROFILE is None:
+    if F_.PROFILE is None or 2.0 * B * Hs * Ws * kh * kw * Cp * Cg < F_.PROFILE_MIN_FLOP:
         L.check(lib.lic_wgrad_bf16(C.byref(d), _ptr(ws), nbytes, _stream()), "lic_wgrad_bf16")
         return
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -91,6 +91,8 @@ class Trainer:
         if self.distributed and dist.get_world_size() > 1:
             broadcast_parameters(self.model)
             self.reducer = GradientAllReducer(self.model.parameters())
+            if hasattr(self.model, "overlap_branches"):
+                self.model.overlap_branches = False  # single-stream under DP until validated next to RCCL
         self.writer = writer if writer is not None else (_make_writer(log_dir, self.step) if self.rank == 0 else None)
 
     # -- checkpointing (Trainer.py:52-71) --------------------------------------------------------
