@@ -44,6 +44,36 @@ def full():
     red.finish()
 
 
+def pieces():
+    """red.finish() taken apart, host-timed with a device sync after each piece"""
+    fwdbwd()
+    torch.cuda.synchronize()
+    out = {}
+    t0 = time.perf_counter()
+    ps = [p for p in model.parameters()]
+    flat = torch.cat([p.grad.reshape(-1) for p in ps])
+    torch.cuda.synchronize()
+    out["cat"] = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    w = dist.all_reduce(flat, async_op=True)
+    w.wait()
+    torch.cuda.synchronize()
+    out["all_reduce(fresh flat)"] = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    off = 0
+    for p in ps:
+        n = p.numel()
+        torch.mul(flat[off:off + n].view_as(p), 0.5, out=p.grad)
+        off += n
+    torch.cuda.synchronize()
+    out["scatter"] = (time.perf_counter() - t0) * 1e3
+    return out
+
+
+pieces()
+pc = pieces()
+if rank == 0:
+    print("pieces:", {k: round(v, 1) for k, v in pc.items()}, flush=True)
 a = t(fwdbwd)
 b = t(full)
 flat = torch.zeros(14_000_000, device=dev)
