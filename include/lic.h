@@ -239,7 +239,7 @@ int lic_rd_loss_bwd(const float* x_hat, const float* x, int64_t ny, int64_t nz, 
 
 /* ---- bf16-storage variants (BASELINE config 3) --------------------------------------------------
  * Activations / auxiliaries are bf16 NHWC (pitches and channel counts multiples of 8), weights are
- * packed to bf16 by lic_pack_weight_bf16 ([tap][ceil(K/64)][ceil64(N)/32][4][64 lanes][8], MFMA operand order), bias and all
+ * packed to bf16 by lic_pack_weight_bf16 ([tap][ceil(K/32)][ceil64(N)/32][2][64 lanes][8], MFMA operand order), bias and all
  * accumulation are fp32 (v_mfma_f32_32x32x16_bf16).  lic_igemm_bf16 supports the NONE / GDN / IGDN
  * / GDN_BWD / IGDN_BWD epilogues (no residual); `out` is bf16, or fp32 when out_f32 != 0.
  * Parameter gradients (lic_wgrad_bf16 dst, lic_colsum_bf16 out) are fp32. */

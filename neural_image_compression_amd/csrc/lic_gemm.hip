@@ -100,7 +100,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   // fused GDN epilogue: x tile [64][BN+4] + one 32x32 patch per wave
   constexpr int SA_FLOATS = (FUSE && 64 * (BN + 4) + 4096 > SA_MAIN) ? 64 * (BN + 4) + 4096 : SA_MAIN;
   static_assert(!FUSE || (VEC && FULLN), "fused GDN epilogue: float4 gathers, full N");
-  __shared__ __attribute__((aligned(16))) float smem[SA_FLOATS];
+  __shared__ __attribute__((aligned(16))) float smem[SA_FLOATS + 32];  // + the decoded tap list
   float(*sA)[BM * IG_LDA] = reinterpret_cast<float(*)[BM * IG_LDA]>(smem);
 
   const int tid = threadIdx.x;
@@ -174,6 +174,18 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   for (int b = 0; b < TN; ++b) n_live += ((n0 + wn0 + b * 32) < p.Npad) ? 1 : 0;
 
   const int ntaps = p.ntaps[phase];
+  // Tap list of this phase, decoded once into LDS as tap | r << 8 | s << 16.  (Indexing the kernarg
+  // array per chunk compiles to a global_load_ubyte + `s_waitcnt vmcnt(0)` -- a memory round trip in
+  // front of every chunk's loads, and a full drain of the DMA queue -- plus a division by kw.)
+  // (kept INSIDE the one staging array: a second __shared__ object next to LDS-DMA buffers makes
+  // hipcc wait vmcnt(0) before every LDS read)
+  int* s_taps = reinterpret_cast<int*>(smem + SA_FLOATS);
+  if (tid < 28) {
+    const int t = p.taps[phase][tid < ntaps ? tid : 0];
+    const int tr = t / p.kw;
+    s_taps[tid] = t | (tr << 8) | ((t - tr * p.kw) << 16);
+  }
+  __syncthreads();
   const int c_first = ks * p.cps;  // this workgroup's slice of the (tap, channel-block) chunk list
   const int nchunks = max(0, min(ntaps * p.cpt, c_first + p.cps) - c_first);
   f32x4 ra[APASS];
@@ -189,8 +201,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   const int last_tap = ntaps - 1, last_cb = p.cpt - 1;
   auto load_a = [&](int tapi, int cb) {
     const bool past = tapi > last_tap;  // cursor ran past the end: harmless duplicate load
-    const int tap = p.taps[phase][past ? last_tap : tapi];
-    const int r = tap / p.kw, s = tap - r * p.kw;
+    const int code = __builtin_amdgcn_readfirstlane(s_taps[past ? last_tap : tapi]);
+    const int tap = code & 0xFF, r = (code >> 8) & 0xFF, s = code >> 16;
     const int ci = (past ? last_cb : cb) * IG_BK + a_c4;
 #pragma unroll
     for (int j = 0; j < APASS; ++j) {
@@ -235,7 +247,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   if (n_live == 0) wlane = p.w + lane * 4;
   auto load_b = [&](f32x4 (&rb)[TN][2], int tapi, int cb) {
     const bool past = tapi > last_tap;
-    const int tap = p.taps[phase][past ? last_tap : tapi];
+    const int tap = __builtin_amdgcn_readfirstlane(s_taps[past ? last_tap : tapi]) & 0xFF;
     const float* src = wlane + ((long)tap * p.cpt + (past ? last_cb : cb)) * p.Npad * IG_BK;
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
@@ -296,9 +308,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     const int gq = ((tid & 3) ^ ((tid >> 4) & 3)) * 4;  // this thread's logical channel offset in a chunk
     auto issue = [&](int tapi, int cb, int buf) {
       const bool past = tapi > last_tap;
-      const int tap = p.taps[phase][past ? last_tap : tapi];
+      const int code = __builtin_amdgcn_readfirstlane(s_taps[past ? last_tap : tapi]);
+      const int tap = code & 0xFF, r = (code >> 8) & 0xFF, s = code >> 16;
       const int cbb = past ? last_cb : cb;
-      const int r = tap / p.kw, s = tap - r * p.kw;
       const int ci = cbb * IG_BK + gq;
       float* dstA = smem + buf * GL_BUF;
 #pragma unroll

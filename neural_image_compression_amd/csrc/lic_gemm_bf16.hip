@@ -1,8 +1,9 @@
 // bf16-storage / fp32-accumulate variants of the implicit-GEMM kernels (BASELINE config 3) on
 // v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate).  igemm: the LDS-DMA structure of
-// lic_gemm.hip's default loop (both operands global -> LDS by `global_load_lds_dwordx4`, two
-// buffers, one barrier per chunk) with a 64-deep K chunk = 128-byte rows (whole cache lines; 4
-// MFMAs of 32 cycles per 32x32 tile per chunk), 2x2 waves, LDS-staged 16-byte epilogue.
+// lic_gemm.hip's default loop (both operands global -> LDS by `global_load_lds_dwordx4`, 2x2 waves,
+// LDS-staged 16-byte epilogue) with 32-deep chunks.  A chunk is only TM*TN*2 MFMAs of 32 cycles per
+// wave -- shorter than a memory round trip -- so, as in the bf16 wgrad below, the DMA runs TWO
+// chunks ahead through a ring of three LDS buffers (counted `s_waitcnt vmcnt`, raw `s_barrier`).
 #include "lic_common.h"
 #include <type_traits>
 
@@ -26,7 +27,7 @@ __device__ __forceinline__ int fdivb(int n, FastDivB f) {
   return (int)(((unsigned long long)(unsigned)n * f.m) >> (31 + f.s));
 }
 
-constexpr int HB_BK = 64;  // bf16 elements per K chunk (128-byte rows)
+constexpr int HB_BK = 32;  // bf16 elements per K chunk (64-byte rows, 2 MFMA K steps)
 
 __device__ __attribute__((aligned(16))) float g_lic_zero16h[4];  // DMA source of padding / tail lanes
 typedef const __attribute__((address_space(1))) void* lich_gptr_t;
@@ -34,7 +35,7 @@ typedef __attribute__((address_space(3))) void* lich_lptr_t;
 
 struct IgemmHParams {
   const bf16_t* in;
-  const bf16_t* w;  // packed [tap][cpt][Npad/32][4][64 lanes][8] bf16
+  const bf16_t* w;  // packed [tap][cpt][Npad/32][2][64 lanes][8] bf16
   const float* bias;
   void* out;        // bf16 or fp32 (out_f32)
   bf16_t* out2;     // GDN norm (bf16)
@@ -66,12 +67,14 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
   constexpr int BN = 64 * TN;
   constexpr int WM = BM / 2, WN = BN / 2;
   constexpr int TM = WM / 32;
-  constexpr int APASS = BM / 32;              // 16-byte DMA pieces per thread per A tile
+  constexpr int APASS = BM / 64;              // 16-byte DMA pieces per thread per A tile
+  constexpr int NL = APASS + TN;              // DMA instructions per thread per chunk
   constexpr int BUF = (BM + BN) * HB_BK;      // bf16 elements of one (A tile, B panel) buffer
-  // two DMA buffers, later reused as the fp32 staging area of the epilogue (4 KiB per wave)
-  constexpr int SA_BYTES = (2 * BUF * 2 > 4 * 4096) ? 2 * BUF * 2 : 4 * 4096;
-  __shared__ __attribute__((aligned(16))) char smem_raw[SA_BYTES];
-  bf16_t* smem = reinterpret_cast<bf16_t*>(smem_raw);
+  // three DMA buffers, later reused as the fp32 staging area of the epilogue (4 KiB per wave);
+  // a plain 2-D array indexed with compile-time buffer numbers, so hipcc can tell the buffers apart
+  constexpr int BUFP = (3 * BUF * 2 >= 4 * 4096) ? BUF : (4 * 4096 / 2 + 2) / 3;
+  __shared__ __attribute__((aligned(16))) bf16_t smem_all[3 * BUFP + 64];  // + the decoded tap list
+  auto bufp = [&](int b) { return smem_all + b * BUFP; };
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -97,16 +100,16 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
   const int py = (p.nphase > 1) ? phase / p.stride : 0;
   const int px = (p.nphase > 1) ? phase % p.stride : 0;
 
-  // A tile image [BM][64] bf16, packed 128-byte rows: thread t of pass j owns row t/8 + 32j,
-  // 16-byte slot t%8 = byte 16t + 4096j, the wave-linear order the DMA writes.  Rows r and r+2
-  // would share banks in a ds_read_b128 lane group, so slot s of row r holds K-octet s ^ ((r>>1)&7):
+  // A tile image [BM][32] bf16, packed 64-byte rows: thread t of pass j owns row t/4 + 64j, 16-byte
+  // slot t%4 = byte 16t + 4096j, the wave-linear order the DMA writes.  Rows r, r+4, r+8, r+12 of a
+  // ds_read_b128 lane group would share banks, so slot s of row r holds K-octet s ^ ((r>>2)&3):
   // applied to the per-lane SOURCE address here and to the fragment reads below.
-  const int gq = ((tid & 7) ^ ((tid >> 4) & 7)) * 8;  // this thread's logical channel offset in a chunk
+  const int gq = ((tid & 3) ^ ((tid >> 4) & 3)) * 8;  // this thread's logical channel offset in a chunk
   int a_base[APASS], a_hy[APASS], a_wx[APASS];
   bool a_ok[APASS];
 #pragma unroll
   for (int j = 0; j < APASS; ++j) {
-    const int prow = m0 + (tid >> 3) + 32 * j;
+    const int prow = m0 + (tid >> 2) + 64 * j;
     a_ok[j] = prow < P;
     const int pr = a_ok[j] ? prow : 0;
     const int b = fdivb(pr, p.dHW[phase]);
@@ -132,46 +135,73 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
   const int ntaps = p.ntaps[phase];
+  // tap list decoded once into LDS (tap | r << 8 | s << 16): a per-chunk kernarg lookup would be a
+  // global load whose wait drains the whole in-order DMA queue
+  // (kept INSIDE the one staging array: a second __shared__ object next to LDS-DMA buffers makes
+  // hipcc wait vmcnt(0) before every LDS read)
+  int* s_taps = reinterpret_cast<int*>(smem_all + 3 * BUFP);
+  if (tid < 28) {
+    const int tt = p.taps[phase][tid < ntaps ? tid : 0];
+    const int tr = tt / p.kw;
+    s_taps[tid] = tt | (tr << 8) | ((tt - tr * p.kw) << 16);
+  }
+  __syncthreads();
   const int nchunks = ntaps * p.cpt;
   const int sgn = p.transposed ? -1 : 1;
   const int sh = (p.transposed && p.stride == 2) ? 1 : 0;
   const int last_tap = ntaps - 1, last_cb = p.cpt - 1;
   const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_lic_zero16h);
-  auto issue = [&](int tapi, int cb, int buf) {
+  // Per-tap gather state: the pixel a row reads changes only when the tap does (every cpt chunks);
+  // inside a tap a chunk just moves 32 channels on.  With 12-18 MFMAs of 32 cycles per chunk the
+  // full address computation (~70 VALU) per chunk would cost as much as the matrix work itself.
+  long t_off[APASS];
+  bool t_ok[APASS];
+  int t_tap = 0;
+  auto issue = [&](int tapi, int cb, auto bufc) {
+    constexpr int buf = decltype(bufc)::value;
     const bool past = tapi > last_tap;  // cursor ran past the end: harmless duplicate DMA into the idle buffer
-    const int tap = p.taps[phase][past ? last_tap : tapi];
     const int cbb = past ? last_cb : cb;
-    const int r = tap / p.kw, s = tap - r * p.kw;
+    if (cb == 0 && !past) {  // wave-uniform: a new tap begins
+      const int code = __builtin_amdgcn_readfirstlane(s_taps[tapi]);
+      const int r = (code >> 8) & 0xFF, s = code >> 16;
+      t_tap = code & 0xFF;
+#pragma unroll
+      for (int j = 0; j < APASS; ++j) {
+        const int nh = a_hy[j] + sgn * r, nw = a_wx[j] + sgn * s;
+        const int ih = nh >> sh, iw = nw >> sh;
+        t_ok[j] = a_ok[j] && nh >= 0 && nw >= 0 && ih < p.Hi && iw < p.Wi;
+        t_off[j] = t_ok[j] ? (long)(a_base[j] + ih * p.Wi + iw) * p.in_ld : 0L;
+      }
+    }
+    const int tap = t_tap;
     const int ci = cbb * HB_BK + gq;
-    bf16_t* dstA = smem + buf * BUF;
+    const bool cok = ci < p.Cin;
+    bf16_t* dstA = bufp(buf);
 #pragma unroll
     for (int j = 0; j < APASS; ++j) {
-      const int nh = a_hy[j] + sgn * r, nw = a_wx[j] + sgn * s;
-      const int ih = nh >> sh, iw = nw >> sh;
-      const bool ok = a_ok[j] && nh >= 0 && nw >= 0 && ih < p.Hi && iw < p.Wi && ci < p.Cin;
-      const int okm = -(int)ok;  // selects, not a branch: the DMA stays in the MFMAs' basic block
-      const long off = (long)((a_base[j] + ih * p.Wi + iw) & okm) * p.in_ld + (ci & okm);
-      const bf16_t* src = (ok ? p.in : zsrc) + off;
+      const bool ok = t_ok[j] && cok;
+      const bf16_t* src = ok ? p.in + t_off[j] + ci : zsrc;
       __builtin_amdgcn_global_load_lds((lich_gptr_t)src, (lich_lptr_t)(dstA + j * 2048 + wave * 512), 16, 0, 0);
     }
     const bf16_t* wsrc = p.w + ((long)tap * p.cpt + cbb) * p.Npad * HB_BK + (long)n0 * HB_BK + tid * 8;
     bf16_t* dstB = dstA + BM * HB_BK;
 #pragma unroll
-    for (int j = 0; j < 2 * TN; ++j)
+    for (int j = 0; j < TN; ++j)
       __builtin_amdgcn_global_load_lds((lich_gptr_t)(wsrc + j * 2048), (lich_lptr_t)(dstB + j * 2048 + wave * 512),
                                        16, 0, 0);
   };
   const bool sq = p.prologue == 1;
-  auto compute = [&](int buf) {
-    const bf16_t* bA = smem + buf * BUF;
-    const bf16_t* bB = bA + BM * HB_BK + (wn0 >> 5) * 2048 + lane * 8;
-    bf16x8 af[TM][4], bf[TN][4];
+  auto compute = [&](auto bufc) {
+    constexpr int buf = decltype(bufc)::value;
+    const bf16_t* bA = bufp(buf);
+    const bf16_t* bB = bA + BM * HB_BK + (wn0 >> 5) * 1024 + lane * 8;
+    bf16x8 af[TM][2], bf[TN][2];
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
       const int row = wm0 + a * 32 + li;
-      const int sw = (row >> 1) & 7;
+      const int sw = (row >> 2) & 3;
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
+      for (int q = 0; q < 2; ++q) {
         af[a][q] = *reinterpret_cast<const bf16x8*>(bA + row * HB_BK + (((q * 2 + lh) ^ sw) * 8));
         if (sq) af[a][q] = sq8(af[a][q]);  // prologue 1 (GDN pool): square at the read
       }
@@ -179,9 +209,9 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
 #pragma unroll
     for (int b = 0; b < TN; ++b)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) bf[b][q] = *reinterpret_cast<const bf16x8*>(bB + (b * 4 + q) * 512);
+      for (int q = 0; q < 2; ++q) bf[b][q] = *reinterpret_cast<const bf16x8*>(bB + (b * 2 + q) * 512);
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int q = 0; q < 2; ++q)
 #pragma unroll
       for (int b = 0; b < TN; ++b)
 #pragma unroll
@@ -197,32 +227,40 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
     }
   };
   if (nchunks > 0) {
-    // per chunk: __syncthreads (vmcnt(0): my DMA of chunk c landed; barrier: everyone's did and everyone
-    // is done reading chunk c-1) -> issue the DMA of chunk c+1 -> MFMAs of chunk c
-    issue(l_tap, l_cb, 0);
+    // Ring of three buffers, unrolled by three so that buffer indices are compile-time constants.
+    // At the top of a step the DMAs of chunks c and c+1 are in flight: vmcnt(NL) retires mine of
+    // chunk c, the barrier says everyone's landed and everyone finished reading chunk c-1, whose
+    // buffer takes chunk c+2 (past-the-end chunks are clamped duplicates, so NL is exact).
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    issue(l_tap, l_cb, I0{});
     advance();
-    int c = 0;
-    for (; c + 1 < nchunks; c += 2) {
-      __syncthreads();
-      issue(l_tap, l_cb, 1);
+    issue(l_tap, l_cb, I1{});
+    advance();
+    auto step = [&](auto cur, auto fill) {
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(NL) : "memory");
+      issue(l_tap, l_cb, fill);
       advance();
-      compute(0);
-      __builtin_amdgcn_sched_barrier(0);  // keep the vmcnt(0)+barrier BEHIND this chunk's MFMAs
-      __syncthreads();
-      issue(l_tap, l_cb, 0);
-      advance();
-      compute(1);
+      compute(cur);
       __builtin_amdgcn_sched_barrier(0);
+    };
+    int c = 0;
+    for (; c + 2 < nchunks; c += 3) {
+      step(I0{}, I2{});
+      step(I1{}, I0{});
+      step(I2{}, I1{});
     }
-    __syncthreads();
-    if (c < nchunks) compute(0);
+    if (c < nchunks) step(I0{}, I2{});
+    if (c + 1 < nchunks) step(I1{}, I0{});
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // the epilogue reuses the buffers
   }
 
   // ---- epilogue: stage each 32x32 fp32 tile through LDS; a lane then owns 8 consecutive
   // channels of a row (16-byte bf16 accesses; fp32 output writes two 16-byte halves) ------------
   const int epi = p.epilogue;
-  float* stg = reinterpret_cast<float*>(smem_raw) + wave * 1024;
+  float* stg = reinterpret_cast<float*>(smem_all) + wave * 1024;
   const int c8 = (lane & 3) * 8, r16 = lane >> 2;
 #pragma unroll
   for (int a = 0; a < TM; ++a)
@@ -303,7 +341,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
 
 static bool al16h(const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
-// ---- weight packing to bf16: dst[tap][chunk][n/32][kstep][lane][8], zero padded (K to 64, N to 64).
+// ---- weight packing to bf16: dst[tap][chunk][n/32][kstep][lane][8], zero padded (K to 32, N to 64).
 // Lane (col = lane&31, h = lane>>5) of a wave owns k = 16*kstep + 8h + e of column 32*tile + col:
 // the B fragment of one 32x32x16 MFMA is lane*16 B of one contiguous KiB.
 __global__ __launch_bounds__(256) void pack_weight_bf16_kernel(const float* src, bf16_t* dst, int taps, int K,
@@ -312,8 +350,8 @@ __global__ __launch_bounds__(256) void pack_weight_bf16_kernel(const float* src,
   const long total = (long)taps * cpt * Npad * HB_BK;
   const int ntile = Npad >> 5;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-    const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), q = (int)((i >> 9) & 3);
-    long t = i >> 11;
+    const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), q = (int)((i >> 9) & 1);
+    long t = i >> 10;
     const int tile = (int)(t % ntile);
     t /= ntile;
     const int cb = (int)(t % cpt);
