@@ -63,6 +63,52 @@ def test_argument_validation_without_gpu(lib):
     assert L.lic_colsum_workspace_bytes(0, 4) == 0
 
 
+def test_argument_validation_of_the_round1_extensions(lib):
+    """fused conv+GDN, bf16, metric, coder-table and pipeline entries: bad arguments -> status codes,
+    plans / sizes are pure host functions"""
+    L = lib.load()
+    assert L.lic_igemm_fused_gdn_supported(192, 192) == 1 and L.lic_igemm_fused_gdn_supported(3, 192) == 0
+    assert L.lic_igemm_fused_gdn_supported(192, 96) == 0
+    assert L.lic_igemm_fused_gdn_preferred(None) == 0
+    d = lib.IgemmDesc()
+    d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout = 32, 64, 64, 192, 32, 32, 192
+    d.kh = d.kw = 5
+    d.stride, d.pad = 2, 2
+    d.in_ld = d.out_ld = d.out2_ld = d.out3_ld = 192
+    assert L.lic_igemm_fused_gdn_preferred(ctypes.byref(d)) == 1          # 32x32 outputs: 64-row tiles anyway
+    d.Hi = d.Wi = 128
+    d.Ho = d.Wo = 64
+    assert L.lic_igemm_fused_gdn_preferred(ctypes.byref(d)) == 0          # the big layers stay two launches
+    buf = ctypes.create_string_buffer(96)
+    assert L.lic_igemm_kernel_name(ctypes.byref(d), buf, 96) == -1         # null operand pointers
+    assert L.lic_wgrad_stage(None, None, 0, 1, None) == -1 and L.lic_wgrad_kernel_name(None, buf, 96) == -1
+    assert L.lic_igemm_bf16(None, 0, None) == -1 and L.lic_wgrad_bf16(None, None, 0, None) == -1
+    assert L.lic_packed_weight_bf16_elems(25, 192, 192) == 25 * 6 * 192 * 32
+    assert L.lic_packed_weight_bf16_elems(1, 80, 75) == 3 * 128 * 32          # K to 32, N to 64
+    assert L.lic_msssim_workspace_bytes(1, 3, 160, 300) == 0                  # side must exceed 160
+    assert L.lic_msssim_workspace_bytes(1, 3, 512, 768) > 0
+    assert L.lic_msssim(None, None, 1, 3, 512, 768, 1, 1, 1, 1, 1.0, None, None, None, 0, None) == -1
+    assert L.lic_factorized_cdf_tables(None, 4, -8, 17, None, None) == -1
+    assert L.lic_gmm_cdf_tables(None, 1, 4, 1, 8, None, None, None) == -1
+    assert L.lic_u8_to_f32(None, None, 16, None) == -1
+    assert L.lic_tensor_stats(None, 16, 8, 0.0, 1.0, None, None, None, 0, None) == -1
+    assert L.lic_tensor_stats_workspace_bytes() == 256 * 6 * 8
+
+
+def test_host_codec_library_exports_its_header():
+    import __graft_entry__ as g
+    g.build_codec()
+    path = os.path.join(ROOT, "neural_image_compression_amd", "liblic_codec.so")
+    txt = re.sub(r"/\*.*?\*/", "", open(os.path.join(ROOT, "include", "lic_codec.h")).read(), flags=re.S)
+    syms = sorted(set(re.findall(r"\b(lic_[a-z0-9_]+)\s*\(", txt)))
+    out = subprocess.check_output(["nm", "-D", "--defined-only", path], text=True)
+    exported = set(re.findall(r"\bT (lic_[a-z0-9_]+)", out))
+    assert syms and not [s for s in syms if s not in exported] and not [s for s in exported if s not in syms]
+    c = ctypes.CDLL(path)
+    assert c.lic_codec_version() == 1
+    assert c.lic_rc_encode(None, None, 4, None, 0, None, 0, None) == -1
+
+
 def test_check_raises_with_status_name(lib):
     with pytest.raises(lib.LicError, match="LIC_ERR_INVALID"):
         lib.check(-1, "probe")
