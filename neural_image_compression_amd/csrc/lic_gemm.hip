@@ -1252,7 +1252,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 //   __syncthreads (vmcnt(0): my DMA of chunk c landed; barrier: everyone's did, and everyone is
 //   done reading chunk c-1)  ->  issue DMA of chunk c+1  ->  MFMAs of chunk c.
 template <int TM, int TN>
-__global__ __launch_bounds__(256) void wgrad_glds_kernel(const WgradParams p) {
+__global__ __launch_bounds__(256, (TM * TN >= 6 ? 2 : 1)) void wgrad_glds_kernel(const WgradParams p) {
   constexpr int BMt = 64 * TM, BNt = 64 * TN, NS = TM + TN;
   constexpr int WM = BMt / 2, WN = BNt / 2;
   __shared__ __attribute__((aligned(16))) float smem[2][NS][WG_BK * 64];
@@ -1426,6 +1426,13 @@ static int wg_plan(const lic_wgrad_desc* d, WgPlan* pl) {
   pl->TM = (pl->vec && pl->Cm > 64 && (pl->Cm % 128 == 0 || pl->Cm > 256)) ? 2 : 1;
   pl->TN = (pl->vec && pl->Cn > 128) ? 3 : (pl->vec && pl->Cn > 64 ? 2 : 1);
   if (pl->TM == 1 && pl->TN == 2) pl->TN = 1;  // instantiated shapes: (2,3) (2,2) (2,1) (1,3) (1,1)
+  // 192 x 192 tiles (LDS-DMA kernel only) when both channel counts are multiples of 192: half the
+  // L2 -> LDS bytes per MFMA of the 64 x 192 tile
+  if (pl->vec && pl->Cm % 192 == 0 && pl->Cn % 192 == 0 && getenv("LIC_WGRAD_NO_GLDS") == nullptr &&
+      getenv("LIC_WGRAD_NO_T33") == nullptr) {
+    pl->TM = 3;
+    pl->TN = 3;
+  }
   pl->MTt = (pl->Cm + 64 * pl->TM - 1) / (64 * pl->TM);
   pl->NTt = (pl->Cn + 64 * pl->TN - 1) / (64 * pl->TN);
   const long Ps = (long)d->B * d->Hs * d->Ws;
@@ -1435,7 +1442,8 @@ static int wg_plan(const lic_wgrad_desc* d, WgPlan* pl) {
   // (75 workgroups per split): 16 splits 2.47 ms, 40 splits 2.31 ms, 64 splits 2.28 ms -- shorter
   // workgroups even out the tail -- while the slab reduction grows by ~1.7 us per split; whole-round
   // counts that are not multiples of 8 (13 splits) lose the XCD-local L2 reuse and were no better.
-  long sk = (2560 + base - 1) / base;
+  const long resident = 256L * (pl->TM == 1 ? 4 : 2);  // workgroups the chip holds at once
+  long sk = (resident * 5 / 2 + base - 1) / base;
   const long max_sk = (pl->nchunks + 15) / 16;  // at least 16 chunks (256 pixels) per split
   if (sk > max_sk) sk = max_sk;
   if (sk < 1) sk = 1;
@@ -1539,6 +1547,8 @@ static int wgrad_run(const lic_wgrad_desc* d, void* workspace, size_t workspace_
   } while (0)
   if (!pl.vec)
     hipLaunchKernelGGL((wgrad_kernel<1, 1, false, false>), grid, block, 0, s, p);
+  else if (pl.TM == 3 && pl.TN == 3)
+    hipLaunchKernelGGL((wgrad_glds_kernel<3, 3>), grid, block, 0, s, p);
   else if (pl.TM == 2 && pl.TN == 3)
     LIC_WGRAD_LAUNCH(2, 3);
   else if (pl.TM == 2 && pl.TN == 2)
