@@ -89,7 +89,10 @@ typedef struct lic_igemm_desc {
   int32_t Ho, Wo, Cout;
   int32_t kh, kw, stride, pad;
   int32_t transposed;
-  int32_t prologue; /* 0: none, 1: square the gathered input */
+  int32_t prologue; /* 0: none, 1: square the gathered input, 2 / 3: GDN / IGDN backward -- the 1x1
+                     * contraction's operand is t = dL/dnorm built on the fly from in = g, aux2 = x,
+                     * aux3 = norm (-0.5 g x norm^-3/2, or 0.5 g x norm^-1/2 for IGDN) and also
+                     * written to out2 for the d-gamma / d-beta launches (replaces lic_gdn_dnorm) */
   int32_t epilogue; /* enum lic_epilogue */
   uint32_t tap_mask; /* bit (r*kw+s) set = tap is live; 0 = all taps (kh*kw <= 32) */
   float slope;       /* LeakyReLU negative slope */

@@ -190,6 +190,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   const int nchunks = max(0, min(ntaps * p.cpt, c_first + p.cps) - c_first);
   f32x4 ra[APASS];
   bool ra_ok[APASS];
+  // prologue 2 (1x1, VEC): the A operand is t = dL/dnorm of a GDN, computed from three streams as
+  // the chunk is staged, and written out once (out2) for the d-gamma / d-beta launches that follow --
+  // the stand-alone lic_gdn_dnorm pass (3 reads + 1 write of the activation) disappears
+  const bool pro2 = p.prologue == 2 || p.prologue == 3;
+  const bool pro_inv = p.prologue == 3;
+  f32x4 rx[APASS], rn[APASS];
+  long rt_off[APASS];
   // this lane's B-operand address inside a (tap, chunk) panel: column n, K-half lh
   const float* wlane = p.w + ((long)((n0 + wn0) >> 5) * 512 + lane * 4);
 
@@ -217,6 +224,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         const int cc = ci & okm;
         ra[j] = *reinterpret_cast<const f32x4*>(p.in + ((long)pixi * p.in_ld + cc));
         ra_ok[j] = ok;
+        if (pro2) {  // wave-uniform: GDN backward, A = dL/dnorm built from (g = in, x = aux2, norm = aux3)
+          rx[j] = *reinterpret_cast<const f32x4*>(p.aux2 + ((long)pixi * p.aux2_ld + cc));
+          rn[j] = *reinterpret_cast<const f32x4*>(p.aux3 + ((long)pixi * p.aux3_ld + cc));
+          rt_off[j] = (long)pixi * p.out2_ld + cc;
+        }
       } else {
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (ok) {
@@ -237,6 +249,19 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     for (int j = 0; j < APASS; ++j) {
       f32x4 v = ra_ok[j] ? ra[j] : zero4;
       v = sq ? v * v : v;
+      if (pro2) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float rs = __builtin_amdgcn_rsqf(rn[j][e]);  // as lic_gdn_dnorm
+          const float gx = ra[j][e] * rx[j][e];
+          v[e] = pro_inv ? 0.5f * gx * rs : -0.5f * gx * rs * (rs * rs);
+        }
+        if (ra_ok[j]) {
+          if (nt == 0) *reinterpret_cast<f32x4*>(p.out2 + rt_off[j]) = v;
+        } else {
+          v = zero4;
+        }
+      }
       *reinterpret_cast<f32x4*>(&sA[buf][((tid >> 2) + 64 * j) * IG_LDA + a_c4]) = v;
     }
   };
@@ -750,6 +775,13 @@ static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& 
   if ((epi == LIC_EPI_GDN_BWD || epi == LIC_EPI_IGDN_BWD) && (!d->aux || !d->aux2 || !d->aux3))
     return LIC_ERR_INVALID;
   if (epi == LIC_EPI_LEAKY && d->res && !d->out2) return LIC_ERR_INVALID;
+  if (d->prologue == 2 || d->prologue == 3) {  // GDN backward: 1x1, float4 path, t -> out2
+    if (!d->aux2 || !d->aux3 || !d->out2) return LIC_ERR_INVALID;
+    if (d->kh != 1 || d->kw != 1 || d->stride != 1 || d->pad != 0 || d->transposed) return LIC_ERR_UNSUPPORTED;
+    if (d->Cin % 4 || d->in_ld % 4 || d->aux2_ld % 4 || d->aux3_ld % 4 || d->out2_ld % 4 || !aligned16(d->in) ||
+        !aligned16(d->aux2) || !aligned16(d->aux3) || !aligned16(d->out2))
+      return LIC_ERR_UNSUPPORTED;
+  }
   const bool fuse = (epi == LIC_EPI_CONV_GDN || epi == LIC_EPI_CONV_IGDN);
   if (fuse) {
     if (!d->aux || !d->aux2 || !d->out2 || d->res || d->prologue) return LIC_ERR_INVALID;
@@ -891,7 +923,7 @@ static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& 
   int max_chunks = 0;
   for (int ph = 0; ph < p.nphase; ++ph) max_chunks = p.ntaps[ph] * p.cpt > max_chunks ? p.ntaps[ph] * p.cpt : max_chunks;
   p.cps = max_chunks > 0 ? max_chunks : 1;
-  const bool simple_epi = (epi == LIC_EPI_NONE || epi == LIC_EPI_LEAKY) && !d->res && !d->out2;
+  const bool simple_epi = (epi == LIC_EPI_NONE || epi == LIC_EPI_LEAKY) && !d->res && !d->out2 && d->prologue < 2;
   // The split factor depends only on per-image geometry (never on the batch size), so an image's
   // result does not depend on which batch it is computed in (bitwise batch-split invariance).
   const long t_img = (((long)d->Ho * d->Wo + 63) / 64) * ((p.Npad + 63) / 64);
@@ -978,7 +1010,7 @@ LIC_EXPORT int lic_igemm_kernel_name(const lic_igemm_desc* d, char* buf, size_t 
   if (!buf || n == 0) return LIC_ERR_INVALID;
   const bool full = (p.Npad % (64 * TN)) == 0;
   const bool fuse = p.epilogue == LIC_EPI_CONV_GDN || p.epilogue == LIC_EPI_CONV_IGDN;
-  const bool glds = full && p.vec && getenv("LIC_IGEMM_NO_GLDS") == nullptr;
+  const bool glds = full && p.vec && p.prologue < 2 && getenv("LIC_IGEMM_NO_GLDS") == nullptr;
   if (!p.vec)
     snprintf(buf, n, "igemm_kernel<64, 1, false, false, false, false>");
   else
@@ -998,7 +1030,7 @@ LIC_EXPORT int lic_igemm(const lic_igemm_desc* d, lic_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)nwg), block(256);
   const bool full = (p.Npad % (64 * TN)) == 0;
-  const bool glds = full && getenv("LIC_IGEMM_NO_GLDS") == nullptr;
+  const bool glds = full && p.prologue < 2 && getenv("LIC_IGEMM_NO_GLDS") == nullptr;
 #define LIC_IGEMM_LAUNCH(bm, tn)                                                        \
   do {                                                                                  \
     if (glds)                                                                           \

@@ -524,14 +524,22 @@ def _gdn_backward(xh, norm, gamma_e, beta_c, gamma_c, g, inverse, beta_bound, ga
     B, H, W, Cc = xh.shape
     P = B * H * W
     t = torch.empty_like(xh)
-    L.check(lib.lic_gdn_dnorm(_ptr(g), _ptr(xh), _ptr(norm), _ptr(t), xh.numel(), int(inverse),
-                              _stream()), "lic_gdn_dnorm")
     dxh = dbeta = dgamma = None
-    if need_dx:
+    if need_dx and Cc % 4 == 0:
+        # one launch: t = dL/dnorm built on the fly as the contraction's operand (and stored for the
+        # parameter gradients), dx = g * rsqrt(norm) + 2 x (t . gamma) in the epilogue
         dxh = torch.empty_like(xh)
-        _igemm(t, _pack_dense(gamma_e), dxh, B=1, Hi=1, Wi=P, Cin=Cc, Ho=1, Wo=P, Cout=Cc, kh=1, kw=1, stride=1,
-               pad=0, transposed=False, epilogue=L.EPI_IGDN_BWD if inverse else L.EPI_GDN_BWD,
-               aux=g, aux2=xh, aux3=norm)
+        _igemm(g, _pack_dense(gamma_e), dxh, B=1, Hi=1, Wi=P, Cin=Cc, Ho=1, Wo=P, Cout=Cc, kh=1, kw=1, stride=1,
+               pad=0, transposed=False, prologue=3 if inverse else 2,
+               epilogue=L.EPI_IGDN_BWD if inverse else L.EPI_GDN_BWD, aux=g, aux2=xh, aux3=norm, out2=t)
+    else:
+        L.check(lib.lic_gdn_dnorm(_ptr(g), _ptr(xh), _ptr(norm), _ptr(t), xh.numel(), int(inverse),
+                                  _stream()), "lic_gdn_dnorm")
+        if need_dx:
+            dxh = torch.empty_like(xh)
+            _igemm(t, _pack_dense(gamma_e), dxh, B=1, Hi=1, Wi=P, Cin=Cc, Ho=1, Wo=P, Cout=Cc, kh=1, kw=1,
+                   stride=1, pad=0, transposed=False, epilogue=L.EPI_IGDN_BWD if inverse else L.EPI_GDN_BWD,
+                   aux=g, aux2=xh, aux3=norm)
     if need_dbeta:
         dbe = _colsum(t, P, Cc)
         dbeta = torch.empty_like(beta_c)
