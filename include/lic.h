@@ -267,6 +267,23 @@ int lic_gdn_dnorm_bf16(const void* g, const void* x, const void* norm, void* t, 
 
 /* ---- misc ---------------------------------------------------------------------------------- */
 /* ------------------------------------------------------------------------------------------
+ * Stand-alone GDN / IGDN (compressai GDN at Components.py:11-44, Layers.py:41,75)
+ * for C in {64,128,192} (lic_gdn_supported): one sweep over the activation per launch, the C x C pool
+ * on MFMA out of an LDS tile.  x, y, norm, g, dx, t: dense [P][C] fp32 (NHWC activations, P = B*H*W).
+ *   lic_gdn_fwd: norm = beta_eff + x^2 . gamma_eff^T; y = x * rsqrt(norm) (inverse: * sqrt(norm)) (+ res)
+ *                gammaT_packed = lic_pack_weight(gamma_eff, taps=1, K=C, N=C, s_k=1, s_n=C)
+ *   lic_gdn_bwd: t = dL/dnorm (written: the d-gamma / d-beta launches read it),
+ *                dx = g * rsqrt(norm) + 2 x (t . gamma_eff)  (inverse: g * sqrt(norm) + ...)
+ *                gamma_packed = lic_pack_weight(gamma_eff, taps=1, K=C, N=C, s_k=C, s_n=1)
+ * Same chunk / k order as lic_igemm's prologue-1 / prologue-2 route, which serves other channel counts.
+ * ------------------------------------------------------------------------------------------ */
+int lic_gdn_supported(int32_t C);
+int lic_gdn_fwd(const float* x, const float* gammaT_packed, const float* beta_eff, const float* res, float* y,
+                float* norm, int64_t P, int32_t C, int32_t inverse, lic_stream_t stream);
+int lic_gdn_bwd(const float* g, const float* x, const float* norm, const float* gamma_packed, float* dx, float* t,
+                int64_t P, int32_t C, int32_t inverse, lic_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * SURVEY 8(f).2 -- tables for an entropy coder (the reference has none), built on the
  * device from the same distributions the likelihood entries evaluate and consumed by the host range
  * coder of include/lic_codec.h.  A table has S symbols (index i <-> integer value lo + i) and S+1

@@ -209,7 +209,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   auto load_a = [&](int tapi, int cb) {
     const bool past = tapi > last_tap;  // cursor ran past the end: harmless duplicate load
     const int code = __builtin_amdgcn_readfirstlane(s_taps[past ? last_tap : tapi]);
-    const int tap = code & 0xFF, r = (code >> 8) & 0xFF, s = code >> 16;
+    const int r = (code >> 8) & 0xFF, s = code >> 16;
     const int ci = (past ? last_cb : cb) * IG_BK + a_c4;
 #pragma unroll
     for (int j = 0; j < APASS; ++j) {

@@ -134,6 +134,18 @@ def _igemm(inp, w_packed, out, *, B, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, 
     PROFILE.append((nm.value.decode(), flops, act_bytes, e0, e1))
 
 
+def _timed(name, flops, act_bytes, launch):
+    """run `launch()`; bracket it with HIP events when bench.py's PROFILE list is active"""
+    if PROFILE is None or flops < PROFILE_MIN_FLOP:
+        launch()
+        return
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    launch()
+    e1.record()
+    PROFILE.append((name, flops, act_bytes, e0, e1))
+
+
 def _wgrad(p, g, dst, *, B, Hs, Ws, Cp, Hl, Wl, Cg, kh, kw, stride, pad, g_is_row, dst_sm, dst_sn,
            dst_stap, sq_p=0, sq_g=0, scale=1.0):
     d = L.WgradDesc()
@@ -486,9 +498,14 @@ class _GDNFn(torch.autograd.Function):
         norm = torch.empty_like(xh)
         resh = None if res is None else _nhwc(res)
         P = B * H * W
-        _igemm(xh, gT, out, B=1, Hi=1, Wi=P, Cin=Cc, Ho=1, Wo=P, Cout=Cc, kh=1, kw=1, stride=1, pad=0,
-               transposed=False, bias=beta_e, prologue=1, epilogue=L.EPI_IGDN if inverse else L.EPI_GDN,
-               out2=norm, aux=xh, res=resh)
+        if lib.lic_gdn_supported(Cc):
+            _timed(f"gdn_kernel<{Cc // 64}, 0>", 2 * P * Cc * Cc, 4 * 3 * P * Cc,
+                   lambda: L.check(lib.lic_gdn_fwd(_ptr(xh), _ptr(gT), _ptr(beta_e), _ptr(resh), _ptr(out), _ptr(norm),
+                                                   P, Cc, int(inverse), _stream()), "lic_gdn_fwd"))
+        else:
+            _igemm(xh, gT, out, B=1, Hi=1, Wi=P, Cin=Cc, Ho=1, Wo=P, Cout=Cc, kh=1, kw=1, stride=1, pad=0,
+                   transposed=False, bias=beta_e, prologue=1, epilogue=L.EPI_IGDN if inverse else L.EPI_GDN,
+                   out2=norm, aux=xh, res=resh)
         ctx.save_for_backward(xh, norm, gamma_e, beta_c, gamma_c)
         ctx.cfg = (inverse, beta_bound, gamma_bound, res is not None)
         return _nchw_view(out)
@@ -525,7 +542,14 @@ def _gdn_backward(xh, norm, gamma_e, beta_c, gamma_c, g, inverse, beta_bound, ga
     P = B * H * W
     t = torch.empty_like(xh)
     dxh = dbeta = dgamma = None
-    if need_dx and Cc % 4 == 0:
+    if need_dx and lib.lic_gdn_supported(Cc):
+        # the dedicated one-sweep kernel: t built from (g, x, norm) as the tile is loaded
+        dxh = torch.empty_like(xh)
+        gp = _pack_dense(gamma_e)
+        _timed(f"gdn_kernel<{Cc // 64}, 1>", 2 * P * Cc * Cc, 4 * 5 * P * Cc,
+               lambda: L.check(lib.lic_gdn_bwd(_ptr(g), _ptr(xh), _ptr(norm), _ptr(gp), _ptr(dxh), _ptr(t), P, Cc,
+                                               int(inverse), _stream()), "lic_gdn_bwd"))
+    elif need_dx and Cc % 4 == 0:
         # one launch: t = dL/dnorm built on the fly as the contraction's operand (and stored for the
         # parameter gradients), dx = g * rsqrt(norm) + 2 x (t . gamma) in the epilogue
         dxh = torch.empty_like(xh)
