@@ -280,8 +280,13 @@ int lic_gdn_dnorm_bf16(const void* g, const void* x, const void* norm, void* t, 
 int lic_gdn_supported(int32_t C);
 int lic_gdn_fwd(const float* x, const float* gammaT_packed, const float* beta_eff, const float* res, float* y,
                 float* norm, int64_t P, int32_t C, int32_t inverse, lic_stream_t stream);
+/* colsum_*_partial (optional, may be NULL): [lic_gdn_bwd_partial_rows(P)][C] per-workgroup column sums of
+ * t and of dx, so that d beta and the d bias of the convolution in front of the GDN need one
+ * lic_colsum over a few thousand rows instead of a pass over the whole activation */
+int64_t lic_gdn_bwd_partial_rows(int64_t P);
 int lic_gdn_bwd(const float* g, const float* x, const float* norm, const float* gamma_packed, float* dx, float* t,
-                int64_t P, int32_t C, int32_t inverse, lic_stream_t stream);
+                float* colsum_t_partial, float* colsum_dx_partial, int64_t P, int32_t C, int32_t inverse,
+                lic_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * SURVEY 8(f).2 -- tables for an entropy coder (the reference has none), built on the

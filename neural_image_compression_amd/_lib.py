@@ -89,7 +89,8 @@ SIGNATURES = {
     "lic_igemm_fused_gdn_preferred": (C.c_int, [C.POINTER(IgemmDesc)]),
     "lic_gdn_supported": (C.c_int, [_i32]),
     "lic_gdn_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
-    "lic_gdn_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "lic_gdn_bwd_partial_rows": (_i64, [_i64]),
+    "lic_gdn_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "lic_factorized_cdf_tables": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "lic_gmm_cdf_tables": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "lic_msssim_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),

@@ -26,6 +26,8 @@ struct GdnParams {
   const float* res;    // fwd: optional residual added to y
   float* out;          // fwd: y; bwd: dx
   float* out2;         // fwd: norm; bwd: t
+  float* cs_t;         // bwd, optional: per-workgroup column sums of t   [gridDim.x][C] (-> d beta)
+  float* cs_dx;        // bwd, optional: per-workgroup column sums of dx  [gridDim.x][C] (-> the conv's d bias)
   long P;              // pixels
   int inverse;
 };
@@ -81,6 +83,12 @@ __global__ __launch_bounds__(256) void gdn_kernel(const GdnParams p) {
     }
   }
   __syncthreads();
+  if (MODE == 1 && p.cs_t && tid < C) {  // column sums of the t tile (rows past P are zero), fixed order
+    float a = 0.0f;
+#pragma unroll 8
+    for (int r = 0; r < GD_BM; ++r) a += smem[r * LDX + tid];
+    p.cs_t[(long)blockIdx.x * C + tid] = a;
+  }
 
   // ---- pool: acc[32 x 32*TN per wave] = A . panel, A = x^2 (forward) or t (backward) --------------
   f32x16 acc[TN];
@@ -130,6 +138,9 @@ __global__ __launch_bounds__(256) void gdn_kernel(const GdnParams p) {
   if (MODE == 1) __syncthreads();
   float* stg = MODE == 0 ? patch[wave] : smem + wave * 1024;
   const int c4 = (lane & 7) * 4, r8 = lane >> 3;
+  f32x4 csum[TN];  // backward: this lane's share of the column sums of dx
+#pragma unroll
+  for (int b = 0; b < TN; ++b) csum[b] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int b = 0; b < TN; ++b) {
 #pragma unroll
@@ -161,10 +172,27 @@ __global__ __launch_bounds__(256) void gdn_kernel(const GdnParams p) {
           const float f = inv ? __builtin_amdgcn_sqrtf(n4[e]) : __builtin_amdgcn_rsqf(n4[e]);
           o[e] = g4[e] * f + 2.0f * x4[e] * s4[e];
         }
+        csum[b] += o;
       }
       *reinterpret_cast<f32x4*>(p.out + off) = o;
     }
     __builtin_amdgcn_wave_barrier();
+  }
+  if (MODE == 1 && p.cs_dx) {
+    // lanes with equal lane%8 own the same 4 columns (8 row groups), the two wave rows the same columns:
+    // park the 16 partials per column in LDS and add them in a fixed order
+    __syncthreads();  // every wave is done with its patch
+    float* part = smem;  // [2 wave rows][8 row groups][C]
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+      *reinterpret_cast<f32x4*>(&part[(((wave >> 1) * 8 + r8) * C) + wn0 + b * 32 + c4]) = csum[b];
+    __syncthreads();
+    if (tid < C) {
+      float a = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) a += part[k * C + tid];
+      p.cs_dx[(long)blockIdx.x * C + tid] = a;
+    }
   }
 }
 
@@ -193,17 +221,20 @@ LIC_EXPORT int lic_gdn_fwd(const float* x, const float* gammaT_packed, const flo
   if (!gd_al16(x) || !gd_al16(gammaT_packed) || !gd_al16(beta_eff) || !gd_al16(y) || !gd_al16(norm) || !gd_al16(res))
     return LIC_ERR_INVALID;
   if (P > 0x7FFFFFFFL * 32) return LIC_ERR_UNSUPPORTED;
-  GdnParams p{x, nullptr, nullptr, gammaT_packed, beta_eff, res, y, norm, (long)P, inverse};
+  GdnParams p{x, nullptr, nullptr, gammaT_packed, beta_eff, res, y, norm, nullptr, nullptr, (long)P, inverse};
   return gdn_launch<0>(p, C, (hipStream_t)stream);
 }
 
+LIC_EXPORT int64_t lic_gdn_bwd_partial_rows(int64_t P) { return P <= 0 ? 0 : cdiv64(P, GD_BM); }
+
 LIC_EXPORT int lic_gdn_bwd(const float* g, const float* x, const float* norm, const float* gamma_packed, float* dx,
-                           float* t, int64_t P, int32_t C, int32_t inverse, lic_stream_t stream) {
+                           float* t, float* colsum_t_partial, float* colsum_dx_partial, int64_t P, int32_t C,
+                           int32_t inverse, lic_stream_t stream) {
   if (!g || !x || !norm || !gamma_packed || !dx || !t || P <= 0) return LIC_ERR_INVALID;
   if (!lic_gdn_supported(C)) return LIC_ERR_UNSUPPORTED;
   if (!gd_al16(g) || !gd_al16(x) || !gd_al16(norm) || !gd_al16(gamma_packed) || !gd_al16(dx) || !gd_al16(t))
     return LIC_ERR_INVALID;
   if (P > 0x7FFFFFFFL * 32) return LIC_ERR_UNSUPPORTED;
-  GdnParams p{x, g, norm, gamma_packed, nullptr, nullptr, dx, t, (long)P, inverse};
+  GdnParams p{x, g, norm, gamma_packed, nullptr, nullptr, dx, t, colsum_t_partial, colsum_dx_partial, (long)P, inverse};
   return gdn_launch<1>(p, C, (hipStream_t)stream);
 }

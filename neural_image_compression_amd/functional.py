@@ -231,6 +231,8 @@ class _ConvFn(torch.autograd.Function):
         g = _nhwc(gy)
         if leaky:
             g = _leaky_bwd(yh, g, slope)
+        elif hasattr(gy, "_lic_colsum_partial") and not has_res:
+            g._lic_colsum_partial = gy._lic_colsum_partial
         dx, dw, db = _conv_backward(xh, weight, g, stride, pad, transposed, tap_mask,
                                     ctx.needs_input_grad[0], ctx.needs_input_grad[1],
                                     has_bias and ctx.needs_input_grad[2])
@@ -260,8 +262,16 @@ def _conv_backward(xh, weight, g, stride, pad, transposed, tap_mask, need_dx, ne
             _wgrad(g, xh, dw, B=B, Hs=Ho, Ws=Wo, Cp=Cout, Hl=Hi, Wl=Wi, Cg=Cin, kh=kh, kw=kw,
                    stride=stride, pad=pad, g_is_row=True, dst_sm=taps, dst_sn=Cin * taps, dst_stap=1)
     if need_db:
-        db = _colsum(g, B * Ho * Wo, Cout)
+        db = _bias_grad(g, B * Ho * Wo, Cout)
     return dx, dw, db
+
+
+def _bias_grad(g, P, Cout):
+    """column sums of the output gradient; from the GDN backward's per-workgroup partials when it left them"""
+    part = getattr(g, "_lic_colsum_partial", None)
+    if part is not None and part.shape[1] == Cout:
+        return _colsum(part, part.shape[0], Cout)
+    return _colsum(g, P, Cout)
 
 
 def conv2d(x, weight, bias, stride=1, padding=0, leaky=False, slope=0.01, tap_mask=0, residual=None):
@@ -321,7 +331,7 @@ def _image_conv_backward(col, weight, g, stride, pad, in_shape, need_dx, need_dw
         dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
         _permute3(tmp, dw, (taps, Cin, Cout), (Cin * Cout, Cout, 1), (1, taps, Cin * taps))
     if need_db:
-        db = _colsum(g, P, Cout)
+        db = _bias_grad(g, P, Cout)
     return dx, dw, db
 
 
@@ -352,6 +362,8 @@ class _ImageConvFn(torch.autograd.Function):
         g = _nhwc(gy)
         if leaky:
             g = _leaky_bwd(yh, g, slope)
+        elif hasattr(gy, "_lic_colsum_partial"):
+            g._lic_colsum_partial = gy._lic_colsum_partial
         dx, dw, db = _image_conv_backward(col, weight, g, stride, pad, in_shape, ctx.needs_input_grad[0],
                                           ctx.needs_input_grad[1], has_bias and ctx.needs_input_grad[2])
         return dx, dw, db, None, None, None, None
@@ -517,7 +529,10 @@ class _GDNFn(torch.autograd.Function):
         dxh, dbeta, dgamma = _gdn_backward(xh, norm, gamma_e, beta_c, gamma_c, _nhwc(gy), inverse, beta_bound,
                                            gamma_bound, *ctx.needs_input_grad[:3])
         dres = gy if has_res else None
-        return (None if dxh is None else _nchw_view(dxh)), dbeta, dgamma, None, None, None, None, dres
+        dx = None if dxh is None else _nchw_view(dxh)
+        if dx is not None and hasattr(dxh, "_lic_colsum_partial"):
+            dx._lic_colsum_partial = dxh._lic_colsum_partial  # rides along to the producing conv's backward
+        return dx, dbeta, dgamma, None, None, None, None, dres
 
 
 def _gdn_reparam(beta, gamma, beta_bound, gamma_bound, pedestal):
@@ -542,13 +557,22 @@ def _gdn_backward(xh, norm, gamma_e, beta_c, gamma_c, g, inverse, beta_bound, ga
     P = B * H * W
     t = torch.empty_like(xh)
     dxh = dbeta = dgamma = None
+    cs_dx = None
+    dbe = None
     if need_dx and lib.lic_gdn_supported(Cc):
-        # the dedicated one-sweep kernel: t built from (g, x, norm) as the tile is loaded
+        # the dedicated one-sweep kernel: t built from (g, x, norm) as the tile is loaded; it also emits
+        # per-workgroup column sums of t (-> d beta) and of dx (-> the d bias of the conv in front)
         dxh = torch.empty_like(xh)
         gp = _pack_dense(gamma_e)
+        rows = lib.lic_gdn_bwd_partial_rows(P)
+        pt = torch.empty((rows, Cc), device=xh.device, dtype=torch.float32)
+        pdx = torch.empty((rows, Cc), device=xh.device, dtype=torch.float32)
         _timed(f"gdn_kernel<{Cc // 64}, 1>", 2 * P * Cc * Cc, 4 * 5 * P * Cc,
-               lambda: L.check(lib.lic_gdn_bwd(_ptr(g), _ptr(xh), _ptr(norm), _ptr(gp), _ptr(dxh), _ptr(t), P, Cc,
-                                               int(inverse), _stream()), "lic_gdn_bwd"))
+               lambda: L.check(lib.lic_gdn_bwd(_ptr(g), _ptr(xh), _ptr(norm), _ptr(gp), _ptr(dxh), _ptr(t), _ptr(pt),
+                                               _ptr(pdx), P, Cc, int(inverse), _stream()), "lic_gdn_bwd"))
+        if need_dbeta:
+            dbe = _colsum(pt, rows, Cc)
+        cs_dx = pdx
     elif need_dx and Cc % 4 == 0:
         # one launch: t = dL/dnorm built on the fly as the contraction's operand (and stored for the
         # parameter gradients), dx = g * rsqrt(norm) + 2 x (t . gamma) in the epilogue
@@ -565,7 +589,8 @@ def _gdn_backward(xh, norm, gamma_e, beta_c, gamma_c, g, inverse, beta_bound, ga
                    stride=1, pad=0, transposed=False, epilogue=L.EPI_IGDN_BWD if inverse else L.EPI_GDN_BWD,
                    aux=g, aux2=xh, aux3=norm)
     if need_dbeta:
-        dbe = _colsum(t, P, Cc)
+        if dbe is None:
+            dbe = _colsum(t, P, Cc)
         dbeta = torch.empty_like(beta_c)
         L.check(lib.lic_gdn_reparam_bwd(_ptr(beta_c), _ptr(dbe), _ptr(dbeta), Cc, beta_bound,
                                         _stream()), "lic_gdn_reparam_bwd")
@@ -576,6 +601,8 @@ def _gdn_backward(xh, norm, gamma_e, beta_c, gamma_c, g, inverse, beta_bound, ga
         dgamma = torch.empty_like(gamma_c)
         L.check(lib.lic_gdn_reparam_bwd(_ptr(gamma_c), _ptr(dge), _ptr(dgamma), Cc * Cc, gamma_bound,
                                         _stream()), "lic_gdn_reparam_bwd")
+    if cs_dx is not None and dxh is not None:
+        dxh._lic_colsum_partial = cs_dx  # [rows][C] partial column sums of dx: the conv in front needs only these
     return dxh, dbeta, dgamma
 
 
