@@ -1423,7 +1423,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, f
 long lic_pick_splits(long base, long slots, long max_sk) {
   long best = 1;
   double best_eff = 0.0;
-  if (max_sk > 256) max_sk = 256;
+  if (max_sk > 512) max_sk = 512;
   if (max_sk < 1) max_sk = 1;
   for (long r = 1; r <= 4; ++r) {
     long sk = (r * slots) / base;
@@ -1460,8 +1460,9 @@ static int wg_plan(const lic_wgrad_desc* d, WgPlan* pl) {
   if (pl->TM == 1 && pl->TN == 2) pl->TN = 1;  // instantiated shapes: (2,3) (2,2) (2,1) (1,3) (1,1)
   // 192 x 192 tiles (LDS-DMA kernel only) when both channel counts are multiples of 192: half the
   // L2 -> LDS bytes per MFMA of the 64 x 192 tile
+  const long chunks16 = ((long)d->B * d->Hs * d->Ws + 255) / 256;  // splits of >= 16 chunks available
   if (pl->vec && pl->Cm % 192 == 0 && pl->Cn % 192 == 0 && getenv("LIC_WGRAD_NO_GLDS") == nullptr &&
-      getenv("LIC_WGRAD_NO_T33") == nullptr) {
+      getenv("LIC_WGRAD_NO_T33") == nullptr && chunks16 * pl->ntaps >= 512) {  // else too few workgroups
     pl->TM = 3;
     pl->TN = 3;
   }
@@ -1481,6 +1482,11 @@ static int wg_plan(const lic_wgrad_desc* d, WgPlan* pl) {
   if (sk < 1) sk = 1;
   if (sk > 256) sk = 256;
   if (sk > 8) sk = (sk + 7) & ~7L;  // whole splits per XCD (see the kernel's remap)
+  // 128/192-row tiles (512 resident workgroups): whole rounds of the machine matter more than anything
+  // else.  Measured on the 192x192 tile, 25 workgroups per split: 20 splits (0.98 rounds) 2.09 ms,
+  // 32 (1.56) 2.55 ms, 40 (1.95) 2.06 ms, 56 (2.73) 2.21 ms, 61 (2.98) 2.08 ms -- so take the fewest
+  // rounds that fill >= 90 %, which also keeps the slab reduction small.
+  if (pl->TM >= 2) sk = lic_pick_splits(base, resident, max_sk);
   if (const char* e = getenv("LIC_WGRAD_SPLITS")) sk = atol(e) > 0 ? atol(e) : sk;  // tuning aid
   if (sk > max_sk) sk = max_sk;
   pl->cps = (int)((pl->nchunks + sk - 1) / sk);
