@@ -331,22 +331,37 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     // banks, so slot s of row r holds K-quad s ^ ((r >> 2) & 3): the swizzle is applied to the
     // per-lane SOURCE address here and to the fragment reads below.
     const int gq = ((tid & 3) ^ ((tid >> 4) & 3)) * 4;  // this thread's logical channel offset in a chunk
+    // Per-tap gather state: the pixel a row reads changes only with the tap (every cpt chunks); within a
+    // tap a chunk moves 16 channels on, so the ~60 VALU of the full address computation run once per
+    // tap instead of once per chunk (wave-uniform branch; `ks` splits may start mid-tap: t_tapi).
+    long t_off[APASS];
+    bool t_ok[APASS];
+    int t_tap = 0, t_tapi = -1;
     auto issue = [&](int tapi, int cb, int buf) {
       const bool past = tapi > last_tap;
-      const int code = __builtin_amdgcn_readfirstlane(s_taps[past ? last_tap : tapi]);
-      const int tap = code & 0xFF, r = (code >> 8) & 0xFF, s = code >> 16;
       const int cbb = past ? last_cb : cb;
+      const int tcur = past ? last_tap : tapi;
+      if (tcur != t_tapi) {  // a new tap begins
+        t_tapi = tcur;
+        const int code = __builtin_amdgcn_readfirstlane(s_taps[tcur]);
+        const int r = (code >> 8) & 0xFF, s = code >> 16;
+        t_tap = code & 0xFF;
+#pragma unroll
+        for (int j = 0; j < APASS; ++j) {
+          const int nh = a_hy[j] + sgn * r, nw = a_wx[j] + sgn * s;
+          const int ih = nh >> sh, iw = nw >> sh;
+          t_ok[j] = a_ok[j] && nh >= 0 && nw >= 0 && ih < p.Hi && iw < p.Wi;
+          t_off[j] = t_ok[j] ? (long)(a_base[j] + ih * p.Wi + iw) * p.in_ld : 0L;
+        }
+      }
+      const int tap = t_tap;
       const int ci = cbb * IG_BK + gq;
+      const bool cok = ci < p.Cin;
       float* dstA = smem + buf * GL_BUF;
 #pragma unroll
       for (int j = 0; j < APASS; ++j) {
-        const int nh = a_hy[j] + sgn * r, nw = a_wx[j] + sgn * s;
-        const int ih = nh >> sh, iw = nw >> sh;
-        const bool ok = a_ok[j] && nh >= 0 && nw >= 0 && ih < p.Hi && iw < p.Wi && ci < p.Cin;
-        // selects, not a branch: the DMA must stay in the MFMAs' basic block
-        const int okm = -(int)ok;
-        const long off = (long)((a_base[j] + ih * p.Wi + iw) & okm) * p.in_ld + (ci & okm);
-        const float* src = (ok ? p.in : g_lic_zero16) + off;
+        const bool ok = t_ok[j] && cok;
+        const float* src = ok ? p.in + t_off[j] + ci : g_lic_zero16;
         __builtin_amdgcn_global_load_lds((lic_gptr_t)src, (lic_lptr_t)(dstA + j * 1024 + wave * 256), 16, 0, 0);
       }
       const float* wsrc = p.w + ((long)tap * p.cpt + cbb) * p.Npad * IG_BK + (long)n0 * IG_BK + tid * 4;
