@@ -381,8 +381,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         const int sw = (row >> 2) & 3;
         af[a][0] = *reinterpret_cast<const f32x4*>(bA + row * IG_BK + (((lh * 2) ^ sw) * 4));
         af[a][1] = *reinterpret_cast<const f32x4*>(bA + row * IG_BK + (((lh * 2 + 1) ^ sw) * 4));
-        af[a][0] = sq ? af[a][0] * af[a][0] : af[a][0];  // prologue 1 (GDN pool): square at the read
-        af[a][1] = sq ? af[a][1] * af[a][1] : af[a][1];
       }
 #pragma unroll
       for (int b = 0; b < TN; ++b) {
@@ -1025,7 +1023,7 @@ LIC_EXPORT int lic_igemm_kernel_name(const lic_igemm_desc* d, char* buf, size_t 
   if (!buf || n == 0) return LIC_ERR_INVALID;
   const bool full = (p.Npad % (64 * TN)) == 0;
   const bool fuse = p.epilogue == LIC_EPI_CONV_GDN || p.epilogue == LIC_EPI_CONV_IGDN;
-  const bool glds = full && p.vec && p.prologue < 2 && getenv("LIC_IGEMM_NO_GLDS") == nullptr;
+  const bool glds = full && p.vec && p.prologue == 0 && getenv("LIC_IGEMM_NO_GLDS") == nullptr;
   if (!p.vec)
     snprintf(buf, n, "igemm_kernel<64, 1, false, false, false, false>");
   else
@@ -1045,7 +1043,9 @@ LIC_EXPORT int lic_igemm(const lic_igemm_desc* d, lic_stream_t stream) {
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)nwg), block(256);
   const bool full = (p.Npad % (64 * TN)) == 0;
-  const bool glds = full && p.prologue < 2 && getenv("LIC_IGEMM_NO_GLDS") == nullptr;
+  // (prologues run on the register-staged loop: a select per operand element in the DMA loop's fragment
+  // reads cost every launch ~30 VALU per chunk)
+  const bool glds = full && p.prologue == 0 && getenv("LIC_IGEMM_NO_GLDS") == nullptr;
 #define LIC_IGEMM_LAUNCH(bm, tn)                                                        \
   do {                                                                                  \
     if (glds)                                                                           \
