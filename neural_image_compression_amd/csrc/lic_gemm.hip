@@ -1298,7 +1298,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 // wave-linear destination the DMA writes.  Two buffers; each iteration is
 //   __syncthreads (vmcnt(0): my DMA of chunk c landed; barrier: everyone's did, and everyone is
 //   done reading chunk c-1)  ->  issue DMA of chunk c+1  ->  MFMAs of chunk c.
-template <int TM, int TN>
+// SQB: the column operand is squared at the fragment read (GDN d-gamma: t^T . x^2).  A template flag, not a
+// runtime select: 48 multiplies + 48 selects per chunk in every launch cost the plain ones ~5 %.
+template <int TM, int TN, bool SQB = false>
 __global__ __launch_bounds__(256, (TM * TN >= 6 ? 2 : 1)) void wgrad_glds_kernel(const WgradParams p) {
   constexpr int BMt = 64 * TM, BNt = 64 * TN, NS = TM + TN;
   constexpr int WM = BMt / 2, WN = BNt / 2;
@@ -1360,17 +1362,13 @@ __global__ __launch_bounds__(256, (TM * TN >= 6 ? 2 : 1)) void wgrad_glds_kernel
       __builtin_amdgcn_global_load_lds((gptr_t)(colp ? colp + 64 * j : g_lic_zero16),
                                        (lptr_t)&smem[buf][TM + j][wave * 256], 16, 0, 0);
   };
-  const bool sqa = p.row.sq != 0, sqb = p.col.sq != 0;  // GDN d-gamma: squared operand, applied at the read
   auto compute = [&](int buf) {
     float af[TM][8], bf[TN][8];
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
       const int ch = wm0 + a * 32;
 #pragma unroll
-      for (int t = 0; t < 8; ++t) {
-        const float v = smem[buf][ch >> 6][(lh * 8 + t) * 64 + (ch & 63) + li];
-        af[a][t] = sqa ? v * v : v;
-      }
+      for (int t = 0; t < 8; ++t) af[a][t] = smem[buf][ch >> 6][(lh * 8 + t) * 64 + (ch & 63) + li];
     }
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
@@ -1378,7 +1376,7 @@ __global__ __launch_bounds__(256, (TM * TN >= 6 ? 2 : 1)) void wgrad_glds_kernel
 #pragma unroll
       for (int t = 0; t < 8; ++t) {
         const float v = smem[buf][TM + (ch >> 6)][(lh * 8 + t) * 64 + (ch & 63) + li];
-        bf[b][t] = sqb ? v * v : v;
+        bf[b][t] = SQB ? v * v : v;
       }
     }
 #pragma unroll
@@ -1477,7 +1475,8 @@ static int wg_plan(const lic_wgrad_desc* d, WgPlan* pl) {
   // L2 -> LDS bytes per MFMA of the 64 x 192 tile
   const long chunks16 = ((long)d->B * d->Hs * d->Ws + 255) / 256;  // splits of >= 16 chunks available
   if (pl->vec && pl->Cm % 192 == 0 && pl->Cn % 192 == 0 && getenv("LIC_WGRAD_NO_GLDS") == nullptr &&
-      getenv("LIC_WGRAD_NO_T33") == nullptr && chunks16 * pl->ntaps >= 512) {  // else too few workgroups
+      getenv("LIC_WGRAD_NO_T33") == nullptr && chunks16 * pl->ntaps >= 512 &&  // else too few workgroups
+      !(d->g_is_row ? d->sq_g : d->sq_p)) {  // (the DMA kernel squares the column operand only)
     pl->TM = 3;
     pl->TN = 3;
   }
@@ -1536,8 +1535,8 @@ LIC_EXPORT int lic_wgrad_kernel_name(const lic_wgrad_desc* d, char* buf, size_t 
   const bool full = (pl.Cm % (64 * pl.TM) == 0) && (pl.Cn % (64 * pl.TN) == 0);
   if (!pl.vec)
     snprintf(buf, n, "wgrad_kernel<1, 1, false, false>");
-  else if (full && getenv("LIC_WGRAD_NO_GLDS") == nullptr)
-    snprintf(buf, n, "wgrad_glds_kernel<%d, %d>", pl.TM, pl.TN);
+  else if (full && !(d->g_is_row ? d->sq_g : d->sq_p) && getenv("LIC_WGRAD_NO_GLDS") == nullptr)
+    snprintf(buf, n, "wgrad_glds_kernel<%d, %d, %s>", pl.TM, pl.TN, (d->g_is_row ? d->sq_p : d->sq_g) ? "true" : "false");
   else
     snprintf(buf, n, "wgrad_kernel<%d, %d, true, %s>", pl.TM, pl.TN, full ? "true" : "false");
   return LIC_OK;
@@ -1587,11 +1586,13 @@ static int wgrad_run(const lic_wgrad_desc* d, void* workspace, size_t workspace_
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(pl.MTt * pl.NTt * pl.ntaps * pl.splitk), block(256);
   const bool full = (pl.Cm % (64 * pl.TM) == 0) && (pl.Cn % (64 * pl.TN) == 0);
-  const bool glds = full && getenv("LIC_WGRAD_NO_GLDS") == nullptr;
+  const bool glds = full && !p.row.sq && getenv("LIC_WGRAD_NO_GLDS") == nullptr;
   if (stage != 2) {
 #define LIC_WGRAD_LAUNCH(tm, tn)                                                      \
   do {                                                                                \
-    if (glds)                                                                         \
+    if (glds && p.col.sq)                                                             \
+      hipLaunchKernelGGL((wgrad_glds_kernel<tm, tn, true>), grid, block, 0, s, p);    \
+    else if (glds)                                                                    \
       hipLaunchKernelGGL((wgrad_glds_kernel<tm, tn>), grid, block, 0, s, p);          \
     else if (full)                                                                    \
       hipLaunchKernelGGL((wgrad_kernel<tm, tn, true, true>), grid, block, 0, s, p);   \
@@ -1600,6 +1601,8 @@ static int wgrad_run(const lic_wgrad_desc* d, void* workspace, size_t workspace_
   } while (0)
   if (!pl.vec)
     hipLaunchKernelGGL((wgrad_kernel<1, 1, false, false>), grid, block, 0, s, p);
+  else if (pl.TM == 3 && pl.TN == 3 && p.col.sq)
+    hipLaunchKernelGGL((wgrad_glds_kernel<3, 3, true>), grid, block, 0, s, p);
   else if (pl.TM == 3 && pl.TN == 3)
     hipLaunchKernelGGL((wgrad_glds_kernel<3, 3>), grid, block, 0, s, p);
   else if (pl.TM == 2 && pl.TN == 3)
