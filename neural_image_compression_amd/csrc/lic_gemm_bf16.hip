@@ -62,7 +62,9 @@ __device__ __forceinline__ bf16x8 sq8(bf16x8 v) {
   return o;
 }
 
-template <int BM, int TN>
+// SQ: prologue 1 (GDN pool: the operand is x^2), squared at the fragment read.  A template flag: as a
+// runtime condition hipcc computes the squares in every launch and selects (100 VALU per 12-MFMA chunk).
+template <int BM, int TN, bool SQ = false>
 __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
   constexpr int BN = 64 * TN;
   constexpr int WM = BM / 2, WN = BN / 2;
@@ -190,7 +192,6 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
       __builtin_amdgcn_global_load_lds((lich_gptr_t)(wsrc + j * 2048), (lich_lptr_t)(dstB + j * 2048 + wave * 512),
                                        16, 0, 0);
   };
-  const bool sq = p.prologue == 1;
   auto compute = [&](auto bufc) {
     constexpr int buf = decltype(bufc)::value;
     const bf16_t* bA = bufp(buf);
@@ -203,7 +204,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         af[a][q] = *reinterpret_cast<const bf16x8*>(bA + row * HB_BK + (((q * 2 + lh) ^ sw) * 8));
-        if (sq) af[a][q] = sq8(af[a][q]);  // prologue 1 (GDN pool): square at the read
+        if constexpr (SQ) af[a][q] = sq8(af[a][q]);
       }
     }
 #pragma unroll
@@ -469,7 +470,13 @@ LIC_EXPORT int lic_igemm_bf16(const lic_igemm_desc* d, int32_t out_f32, lic_stre
   if (nwg > 0x7FFFFFFFL) return LIC_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)nwg), block(256);
-#define LIC_IGEMMH_LAUNCH(bm, tn) hipLaunchKernelGGL((igemm_bf16_kernel<bm, tn>), grid, block, 0, s, p)
+#define LIC_IGEMMH_LAUNCH(bm, tn)                                                        \
+  do {                                                                                   \
+    if (p.prologue == 1)                                                                 \
+      hipLaunchKernelGGL((igemm_bf16_kernel<bm, tn, true>), grid, block, 0, s, p);       \
+    else                                                                                 \
+      hipLaunchKernelGGL((igemm_bf16_kernel<bm, tn>), grid, block, 0, s, p);             \
+  } while (0)
   if (BM == 128 && TN == 3)
     LIC_IGEMMH_LAUNCH(128, 3);
   else if (BM == 64 && TN == 3)
