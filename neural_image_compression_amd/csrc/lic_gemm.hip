@@ -1300,7 +1300,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
 //   done reading chunk c-1)  ->  issue DMA of chunk c+1  ->  MFMAs of chunk c.
 // SQB: the column operand is squared at the fragment read (GDN d-gamma: t^T . x^2).  A template flag, not a
 // runtime select: 48 multiplies + 48 selects per chunk in every launch cost the plain ones ~5 %.
-template <int TM, int TN, bool SQB = false>
+// FULL: every tile is complete (channel counts multiples of the tile); otherwise channels past C are
+// DMA'd from the zero page and the slab writes are guarded (288- and 640-channel layers).
+template <int TM, int TN, bool SQB = false, bool FULL = true>
 __global__ __launch_bounds__(256, (TM * TN >= 6 ? 2 : 1)) void wgrad_glds_kernel(const WgradParams p) {
   constexpr int BMt = 64 * TM, BNt = 64 * TN, NS = TM + TN;
   constexpr int WM = BMt / 2, WN = BNt / 2;
@@ -1354,13 +1356,17 @@ __global__ __launch_bounds__(256, (TM * TN >= 6 ? 2 : 1)) void wgrad_glds_kernel
                             ? p.col.ptr + (p.col.gathered ? gpix : pix) * p.col.ld + n0 + c16
                             : nullptr;
 #pragma unroll
-    for (int j = 0; j < TM; ++j)
-      __builtin_amdgcn_global_load_lds((gptr_t)(rowp ? rowp + 64 * j : g_lic_zero16),
+    for (int j = 0; j < TM; ++j) {
+      const bool ok = rowp && (FULL || m0 + c16 + 64 * j < p.row.C);
+      __builtin_amdgcn_global_load_lds((gptr_t)(ok ? rowp + 64 * j : g_lic_zero16),
                                        (lptr_t)&smem[buf][j][wave * 256], 16, 0, 0);
+    }
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
-      __builtin_amdgcn_global_load_lds((gptr_t)(colp ? colp + 64 * j : g_lic_zero16),
+    for (int j = 0; j < TN; ++j) {
+      const bool ok = colp && (FULL || n0 + c16 + 64 * j < p.col.C);
+      __builtin_amdgcn_global_load_lds((gptr_t)(ok ? colp + 64 * j : g_lic_zero16),
                                        (lptr_t)&smem[buf][TM + j][wave * 256], 16, 0, 0);
+    }
   };
   auto compute = [&](int buf) {
     float af[TM][8], bf[TN][8];
@@ -1410,8 +1416,12 @@ __global__ __launch_bounds__(256, (TM * TN >= 6 ? 2 : 1)) void wgrad_glds_kernel
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const int m = m0 + wm0 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
+      if (!FULL && m >= p.row.C) continue;
 #pragma unroll
-      for (int b = 0; b < TN; ++b) slab[(long)m * p.col.C + n0 + wn0 + b * 32 + li] = acc[a][b][q];
+      for (int b = 0; b < TN; ++b) {
+        const int n = n0 + wn0 + b * 32 + li;
+        if (FULL || n < p.col.C) slab[(long)m * p.col.C + n] = acc[a][b][q];
+      }
     }
 }
 
@@ -1544,8 +1554,9 @@ LIC_EXPORT int lic_wgrad_kernel_name(const lic_wgrad_desc* d, char* buf, size_t 
   const bool full = (pl.Cm % (64 * pl.TM) == 0) && (pl.Cn % (64 * pl.TN) == 0);
   if (!pl.vec)
     snprintf(buf, n, "wgrad_kernel<1, 1, false, false>");
-  else if (full && !(d->g_is_row ? d->sq_g : d->sq_p) && getenv("LIC_WGRAD_NO_GLDS") == nullptr)
-    snprintf(buf, n, "wgrad_glds_kernel<%d, %d, %s>", pl.TM, pl.TN, (d->g_is_row ? d->sq_p : d->sq_g) ? "true" : "false");
+  else if (!(d->g_is_row ? d->sq_g : d->sq_p) && getenv("LIC_WGRAD_NO_GLDS") == nullptr)
+    snprintf(buf, n, "wgrad_glds_kernel<%d, %d, %s, %s>", pl.TM, pl.TN,
+             (d->g_is_row ? d->sq_p : d->sq_g) ? "true" : "false", full ? "true" : "false");
   else
     snprintf(buf, n, "wgrad_kernel<%d, %d, true, %s>", pl.TM, pl.TN, full ? "true" : "false");
   return LIC_OK;
@@ -1595,14 +1606,18 @@ static int wgrad_run(const lic_wgrad_desc* d, void* workspace, size_t workspace_
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(pl.MTt * pl.NTt * pl.ntaps * pl.splitk), block(256);
   const bool full = (pl.Cm % (64 * pl.TM) == 0) && (pl.Cn % (64 * pl.TN) == 0);
-  const bool glds = full && !p.row.sq && getenv("LIC_WGRAD_NO_GLDS") == nullptr;
+  const bool glds = !p.row.sq && getenv("LIC_WGRAD_NO_GLDS") == nullptr;  // (vec is checked below)
   if (stage != 2) {
 #define LIC_WGRAD_LAUNCH(tm, tn)                                                      \
   do {                                                                                \
-    if (glds && p.col.sq)                                                             \
+    if (glds && p.col.sq && full)                                                     \
       hipLaunchKernelGGL((wgrad_glds_kernel<tm, tn, true>), grid, block, 0, s, p);    \
-    else if (glds)                                                                    \
+    else if (glds && p.col.sq)                                                        \
+      hipLaunchKernelGGL((wgrad_glds_kernel<tm, tn, true, false>), grid, block, 0, s, p); \
+    else if (glds && full)                                                            \
       hipLaunchKernelGGL((wgrad_glds_kernel<tm, tn>), grid, block, 0, s, p);          \
+    else if (glds)                                                                    \
+      hipLaunchKernelGGL((wgrad_glds_kernel<tm, tn, false, false>), grid, block, 0, s, p); \
     else if (full)                                                                    \
       hipLaunchKernelGGL((wgrad_kernel<tm, tn, true, true>), grid, block, 0, s, p);   \
     else                                                                              \
