@@ -90,6 +90,8 @@ class GradientAllReducer:
         for b, idxs in enumerate(self.buckets):
             self._work[b].wait()
             flat = self._flat[b]
+            if flat.is_cuda:  # allocated on whichever stream ran the hook; read here on the current one
+                flat.record_stream(torch.cuda.current_stream())
             off = 0
             for i in idxs:
                 p = self.params[i]
