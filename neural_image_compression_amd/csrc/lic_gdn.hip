@@ -11,6 +11,7 @@
 // sums), and finishes in the 16-byte layout.  The generic lic_igemm route (prologue 1 / 2 / 3) remains
 // for other channel counts.
 #include "lic_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -196,6 +197,139 @@ __global__ __launch_bounds__(256) void gdn_kernel(const GdnParams p) {
   }
 }
 
+// Backward with the epilogue operands kept in registers: the tile sweep uses the SAME (row, 4-channel)
+// ownership as the 16-byte epilogue, so each thread still holds g * f(norm) and x for exactly the
+// elements it finishes -- the epilogue issues no loads at all and every stream crosses HBM once
+// (3 reads, 2 writes).  96 more registers: two workgroups per CU instead of three.
+template <int TN>
+__global__ __launch_bounds__(256, 2) void gdn_bwd_reg_kernel(const GdnParams p) {
+  constexpr int C = 64 * TN;
+  constexpr int LDX = C + 4;
+  constexpr int NCH = C / GD_BK;
+  __shared__ __attribute__((aligned(16))) float smem[GD_BM * LDX];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * (32 * TN);
+  const int li = lane & 31, lh = lane >> 5;
+  const int c4 = (lane & 7) * 4, r8 = lane >> 3;
+  const long m0 = (long)blockIdx.x * GD_BM;
+  const bool inv = p.inverse != 0;
+
+  f32x4 u[TN][4], xx[TN][4];  // g * f(norm) and x of this thread's epilogue elements
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    f32x4 gg[4], nn[4];
+    bool ok[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const long pix = m0 + wm0 + it * 8 + r8;
+      ok[it] = pix < p.P;
+      const long off = ok[it] ? pix * C + wn0 + b * 32 + c4 : 0L;
+      xx[b][it] = *reinterpret_cast<const f32x4*>(p.x + off);
+      gg[it] = *reinterpret_cast<const f32x4*>(p.g + off);
+      nn[it] = *reinterpret_cast<const f32x4*>(p.norm + off);
+    }
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int row = wm0 + it * 8 + r8, col = wn0 + b * 32 + c4;
+      f32x4 t;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float rs = __builtin_amdgcn_rsqf(nn[it][e]);  // as lic_gdn_dnorm
+        const float gx = gg[it][e] * xx[b][it][e];
+        t[e] = inv ? 0.5f * gx * rs : -0.5f * gx * rs * (rs * rs);
+        u[b][it][e] = gg[it][e] * (inv ? __builtin_amdgcn_sqrtf(nn[it][e]) : rs);
+      }
+      if (ok[it]) {
+        *reinterpret_cast<f32x4*>(p.out2 + (m0 + row) * C + col) = t;
+      } else {
+        t = f32x4{0.f, 0.f, 0.f, 0.f};
+        u[b][it] = t;
+        xx[b][it] = t;
+      }
+      *reinterpret_cast<f32x4*>(&smem[row * LDX + col]) = t;
+    }
+  }
+  __syncthreads();
+  if (p.cs_t && tid < C) {
+    float a = 0.0f;
+#pragma unroll 8
+    for (int r = 0; r < GD_BM; ++r) a += smem[r * LDX + tid];
+    p.cs_t[(long)blockIdx.x * C + tid] = a;
+  }
+
+  f32x16 acc[TN];
+#pragma unroll
+  for (int b = 0; b < TN; ++b)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[b][r] = 0.0f;
+  const float* glane = p.w + ((long)(wn0 >> 5) * 512 + lane * 4);
+  const float* xrow = smem + (wm0 + li) * LDX + lh * 8;
+  f32x4 g0[TN][2], g1[TN][2];
+  auto load_g = [&](f32x4 (&rg)[TN][2], int c) {
+    const float* src = glane + (long)(c < NCH ? c : NCH - 1) * C * GD_BK;
+#pragma unroll
+    for (int b = 0; b < TN; ++b) {
+      rg[b][0] = *reinterpret_cast<const f32x4*>(src + b * 512);
+      rg[b][1] = *reinterpret_cast<const f32x4*>(src + b * 512 + 256);
+    }
+  };
+  auto pool = [&](int c, const f32x4 (&rg)[TN][2]) {
+    const f32x4 a0 = *reinterpret_cast<const f32x4*>(xrow + c * GD_BK);
+    const f32x4 a1 = *reinterpret_cast<const f32x4*>(xrow + c * GD_BK + 4);
+#pragma unroll
+    for (int t = 0; t < 8; ++t)
+#pragma unroll
+      for (int b = 0; b < TN; ++b)
+        acc[b] = __builtin_amdgcn_mfma_f32_32x32x2f32((t < 4 ? a0 : a1)[t & 3], rg[b][t >> 2][t & 3], acc[b], 0, 0, 0);
+  };
+  load_g(g0, 0);
+#pragma unroll 1
+  for (int c = 0; c < NCH; c += 2) {
+    load_g(g1, c + 1);
+    pool(c, g0);
+    load_g(g0, c + 2);
+    pool(c + 1, g1);
+  }
+  __syncthreads();  // the t tile is dead: the patches alias it
+  float* stg = smem + wave * 1024;
+  f32x4 csum[TN];
+#pragma unroll
+  for (int b = 0; b < TN; ++b) {
+    csum[b] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = acc[b][r];
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+      const int rr = it * 8 + r8;
+      const long pix = m0 + wm0 + rr;
+      if (pix >= p.P) continue;
+      const f32x4 s4 = *reinterpret_cast<const f32x4*>(&stg[rr * 32 + c4]);
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = u[b][it][e] + 2.0f * xx[b][it][e] * s4[e];
+      csum[b] += o;
+      *reinterpret_cast<f32x4*>(p.out + pix * C + wn0 + b * 32 + c4) = o;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (p.cs_dx) {
+    __syncthreads();
+    float* part = smem;  // [2 wave rows][8 row groups][C]
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+      *reinterpret_cast<f32x4*>(&part[(((wave >> 1) * 8 + r8) * C) + wn0 + b * 32 + c4]) = csum[b];
+    __syncthreads();
+    if (tid < C) {
+      float a = 0.0f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) a += part[k * C + tid];
+      p.cs_dx[(long)blockIdx.x * C + tid] = a;
+    }
+  }
+}
+
 bool gd_al16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 template <int MODE>
@@ -236,5 +370,15 @@ LIC_EXPORT int lic_gdn_bwd(const float* g, const float* x, const float* norm, co
     return LIC_ERR_INVALID;
   if (P > 0x7FFFFFFFL * 32) return LIC_ERR_UNSUPPORTED;
   GdnParams p{x, g, norm, gamma_packed, nullptr, nullptr, dx, t, colsum_t_partial, colsum_dx_partial, (long)P, inverse};
-  return gdn_launch<1>(p, C, (hipStream_t)stream);
+  const char* e = getenv("LIC_GDN_BWD_REG");
+  if (e && e[0] == '0') return gdn_launch<1>(p, C, (hipStream_t)stream);  // A/B: epilogue re-reads g, x, norm
+  const unsigned grid = (unsigned)cdiv64(p.P, GD_BM);
+  hipStream_t s = (hipStream_t)stream;
+  if (C == 192)
+    hipLaunchKernelGGL((gdn_bwd_reg_kernel<3>), dim3(grid), dim3(256), 0, s, p);
+  else if (C == 128)
+    hipLaunchKernelGGL((gdn_bwd_reg_kernel<2>), dim3(grid), dim3(256), 0, s, p);
+  else
+    hipLaunchKernelGGL((gdn_bwd_reg_kernel<1>), dim3(grid), dim3(256), 0, s, p);
+  return lic_check_launch();
 }

@@ -567,7 +567,7 @@ def _gdn_backward(xh, norm, gamma_e, beta_c, gamma_c, g, inverse, beta_bound, ga
         rows = lib.lic_gdn_bwd_partial_rows(P)
         pt = torch.empty((rows, Cc), device=xh.device, dtype=torch.float32)
         pdx = torch.empty((rows, Cc), device=xh.device, dtype=torch.float32)
-        _timed(f"gdn_kernel<{Cc // 64}, 1>", 2 * P * Cc * Cc, 4 * 5 * P * Cc,
+        _timed(f"gdn_bwd_reg_kernel<{Cc // 64}>", 2 * P * Cc * Cc, 4 * 5 * P * Cc,
                lambda: L.check(lib.lic_gdn_bwd(_ptr(g), _ptr(xh), _ptr(norm), _ptr(gp), _ptr(dxh), _ptr(t), _ptr(pt),
                                                _ptr(pdx), P, Cc, int(inverse), _stream()), "lic_gdn_bwd"))
         if need_dbeta:
