@@ -66,6 +66,8 @@ struct IgemmParams {
   float* slabs;  // [ksplit][B*Ho*Wo][Cout] fp32
   int MT, NT;  // tiles in M (max over phases) and N
   int bm_unfused;  // host-side note: the M tile the same launch would use without a fused GDN
+  int pgroup;      // 4-phase launches: M tiles per phase-sorted group (0 = rotate phases tile by tile)
+  int porder;      // phase ids by decreasing tap count, 2 bits each
   int ntaps[4];
   int Hq[4], Wq[4];
   FastDiv dHW[4], dW[4];  // divide by Hq*Wq and by Wq
@@ -129,8 +131,22 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   // and the hardware deals consecutive workgroups round-robin over its shader engines / CUs:
   // with a fixed period-4 order one engine would receive only 9-tap workgroups and pace all the
   // others (measured: 1.2 instead of 1.9 resident waves per SIMD).
-  const int phase = (p.nphase == 4) ? ((kq + (kq >> 2) + (kq >> 4) + (kq >> 6) + (kq >> 8)) & 3) : 0;
-  const int mt = kq / p.nphase;
+  int phase = 0, mt = kq;
+  if (p.nphase == 4) {
+    if (p.pgroup > 0) {
+      // phases sorted by tap count inside groups of `pgroup` M tiles: an XCD's 64 slots run a round of
+      // 9-tap workgroups, then the 6-tap ones, then the 4-tap ones -- homogeneous rounds, short tail
+      // (all-equal neighbours also avoid the period-4 pattern described above)
+      const int span = 4 * p.pgroup;
+      const int grp = kq / span, loc = kq - grp * span;
+      const int rank = loc / p.pgroup;
+      phase = (p.porder >> (2 * rank)) & 3;
+      mt = grp * p.pgroup + (loc - rank * p.pgroup);
+    } else {
+      phase = (kq + (kq >> 2) + (kq >> 4) + (kq >> 6) + (kq >> 8)) & 3;
+      mt = kq / p.nphase;
+    }
+  }
   const int Hq = p.Hq[phase], Wq = p.Wq[phase];
   const int P = p.B * Hq * Wq;
   const int m0 = mt * BM, n0 = nt * BN;
@@ -928,6 +944,21 @@ static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& 
   p.bm_unfused = BM_unfused;
   p.NT = (p.Npad + 64 * TN - 1) / (64 * TN);
   p.MT = (int)((maxP + BM - 1) / BM);
+  p.pgroup = 0;
+  p.porder = 0;
+  if (p.nphase == 4 && p.MT >= 128 && getenv("LIC_IGEMM_NO_PSORT") == nullptr) {
+    int ord[4] = {0, 1, 2, 3};
+    for (int i = 0; i < 4; ++i)
+      for (int j = i + 1; j < 4; ++j)
+        if (p.ntaps[ord[j]] > p.ntaps[ord[i]]) {
+          const int t = ord[i];
+          ord[i] = ord[j];
+          ord[j] = t;
+        }
+    p.porder = ord[0] | (ord[1] << 2) | (ord[2] << 4) | (ord[3] << 6);
+    p.pgroup = 64;
+    p.MT = ((p.MT + 63) / 64) * 64;  // whole groups; the padding tiles exit at once
+  }
   nwg = (long)p.MT * p.NT * p.nphase;
   // Small layers (the 16x16 / 8x8 / 4x4 latent side) cannot fill 256 CUs with output tiles alone:
   // split their K loop across workgroups when the caller provided a workspace.
