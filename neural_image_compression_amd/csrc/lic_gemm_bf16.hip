@@ -46,6 +46,7 @@ struct IgemmHParams {
   int B, Hi, Wi, Cin, Ho, Wo, Cout;
   int kw, stride, pad, transposed, prologue, epilogue, out_f32;
   int cpt, Npad, nphase, MT, NT;
+  int pgroup, porder;  // 4-phase launches: phase-sorted groups of `pgroup` M tiles, order 2 bits per rank
   int ntaps[4];
   int Hq[4], Wq[4];
   FastDivB dHW[4], dW[4];
@@ -92,8 +93,19 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
   }
   const int nt = wg % p.NT;
   const int kq = wg / p.NT;
-  const int phase = (p.nphase == 4) ? ((kq + (kq >> 2) + (kq >> 4) + (kq >> 6) + (kq >> 8)) & 3) : 0;
-  const int mt = kq / p.nphase;
+  int phase = 0, mt = kq;
+  if (p.nphase == 4) {
+    if (p.pgroup > 0) {  // phases sorted by tap count inside groups of M tiles (see lic_gemm.hip)
+      const int span = 4 * p.pgroup;
+      const int grp = kq / span, loc = kq - grp * span;
+      const int rank = loc / p.pgroup;
+      phase = (p.porder >> (2 * rank)) & 3;
+      mt = grp * p.pgroup + (loc - rank * p.pgroup);
+    } else {
+      phase = (kq + (kq >> 2) + (kq >> 4) + (kq >> 6) + (kq >> 8)) & 3;
+      mt = kq / p.nphase;
+    }
+  }
   const int Hq = p.Hq[phase], Wq = p.Wq[phase];
   const int P = p.B * Hq * Wq;
   const int m0 = mt * BM, n0 = nt * BN;
@@ -466,6 +478,21 @@ LIC_EXPORT int lic_igemm_bf16(const lic_igemm_desc* d, int32_t out_f32, lic_stre
   p.NT = p.Npad / (64 * TN);
   const int BM = (((maxP + 127) / 128) * p.NT * p.nphase >= 512) ? 128 : 64;
   p.MT = (int)((maxP + BM - 1) / BM);
+  p.pgroup = 0;
+  p.porder = 0;
+  if (p.nphase == 4 && p.MT >= 128) {
+    int ord[4] = {0, 1, 2, 3};
+    for (int i = 0; i < 4; ++i)
+      for (int j = i + 1; j < 4; ++j)
+        if (p.ntaps[ord[j]] > p.ntaps[ord[i]]) {
+          const int t = ord[i];
+          ord[i] = ord[j];
+          ord[j] = t;
+        }
+    p.porder = ord[0] | (ord[1] << 2) | (ord[2] << 4) | (ord[3] << 6);
+    p.pgroup = 64;
+    p.MT = ((p.MT + 63) / 64) * 64;
+  }
   const long nwg = (long)p.MT * p.NT * p.nphase;
   if (nwg > 0x7FFFFFFFL) return LIC_ERR_UNSUPPORTED;
   hipStream_t s = (hipStream_t)stream;
