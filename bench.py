@@ -30,6 +30,11 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# HIP maps streams onto a few hardware queues; once an RCCL communicator exists (its own streams), the two
+# compute streams of the model's decoder / latent-branch overlap ended up serialised unless the queue count
+# is set explicitly (measured: 1286 -> 1350 img/s with RCCL initialised; any value from 2 to 16 does it).
+# Must be in the environment before the HIP runtime starts.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
@@ -150,8 +155,12 @@ def main():
     backend = os.environ.get("LIC_DIST_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    force_red = os.environ.get("LIC_FORCE_REDUCER") == "1"  # one-rank rehearsal of the RCCL data path
+    if world > 1 or force_red:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -164,19 +173,23 @@ def main():
     kind, M, K, B, H, W, lam = CONFIGS[args.config]
     torch.manual_seed(0)
     model = nic.JointAutoregressiveHierarchical(M, K).to(dev)
-    # Two-stream overlap of the decoder with the latent-side branch: on for the single-GPU run, where it
-    # is measured (+4 %); off under data parallelism until it has been validated next to RCCL's stream on
-    # a multi-GPU node (the one-GPU gloo rehearsal stalls in gloo's pinned-host staging with it on).
-    # LIC_OVERLAP=0/1 forces either.
+    # Two-stream overlap of the decoder with the latent-side branch (+4 %).  Also on under RCCL data
+    # parallelism: rehearsed on one rank with the reducer's hooks and collectives forced
+    # (LIC_FORCE_REDUCER=1: 1322 vs 1280 img/s without overlap) -- it needs GPU_MAX_HW_QUEUES set (see the
+    # top of this file).  Off for the gloo rehearsal, where several ranks time-share ONE GPU and every
+    # bucket's exchange waits out the other process's time slice.  LIC_OVERLAP=0/1 forces either.
     ov = os.environ.get("LIC_OVERLAP")
-    model.overlap_branches = (world == 1) if ov is None else (ov == "1")
+    model.overlap_branches = (world == 1 or backend == "nccl") if ov is None else (ov == "1")
     bf16 = args.config in BF16_CONFIGS
     if bf16:
         model.set_precision("bf16")
     broadcast_parameters(model)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
-    reducer = GradientAllReducer(model.parameters(), overlap=os.environ.get("LIC_REDUCER_NO_OVERLAP") != "1") \
-        if world > 1 else None
+    reducer = GradientAllReducer(model.parameters(), overlap=os.environ.get("LIC_REDUCER_NO_OVERLAP") != "1",
+                                 force=force_red, stream_groups=[list(model.decoder.parameters())]) \
+        if (world > 1 or force_red) else None
+    if os.environ.get("LIC_REDUCER_NOOP") == "1":  # diagnostic: process group up, no gradient exchange
+        reducer = None
     g = torch.Generator(device="cpu").manual_seed(1234 + rank)
     x = torch.rand(B, 3, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
 
@@ -276,7 +289,7 @@ def main():
                 line["cpu_baseline"] = {"value": None, "unit": "images/s", "cores": 0, "kind": "port",
                                         "sample": f"failed: {e!r}"}
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if world > 1 or force_red:
         dist.barrier()
         dist.destroy_process_group()
 
