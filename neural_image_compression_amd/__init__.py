@@ -2,6 +2,13 @@
 + rate-distortion hot path of achraf-15/neural_image_compression, behind the reference's own
 Python module surface.  The arithmetic lives in liblic_hip.so (hand-written HIP, C ABI in
 include/lic.h); there is no CPU fallback."""
+import os as _os
+
+# The model overlaps its decoder and latent-side branches on two HIP streams; with an RCCL communicator in
+# the process the runtime serialised them unless the hardware-queue count is set explicitly (DESIGN.md 5).
+# Only effective if this import precedes the first HIP call of the process.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 from .models import JointAutoregressiveHierarchical, HierarchicalMixtureResidual  # noqa: F401
 from .loss import rd_loss  # noqa: F401
 from . import _lib  # noqa: F401
