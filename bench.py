@@ -2,7 +2,7 @@
 """Headline benchmark: images/s of one training step (forward + rd_loss + backward + Adam step)
 of the hot path on synthetic 256x256 RGB batches, batch 32 per GPU.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|3k|2h|4|5] [--no-cpu-baseline]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config 2|3|3k|2h|4|5|hmr] [--no-cpu-baseline]
 
 N > 1 is launched by the driver as  python -m torch.distributed.run --nproc-per-node N ... bench.py
 --gpus N ...: one rank per GPU, images sharded (32 per rank, weak scaling), one RCCL all-reduce of
@@ -50,6 +50,7 @@ CONFIGS = {
     "2h": ("jah", 192, 1, 32, 256, 256, 0.01),   # config 2's model in bf16 storage (not the headline)
     "4": ("jah", 192, 3, 32, 256, 256, 0.01),
     "5": ("jah", 192, 3, 16, 512, 512, 0.01),
+    "hmr": ("hmr", 192, 3, 32, 256, 256, 0.01),  # the 3x3 residual model, for the record
 }
 BF16_CONFIGS = ("3", "2h")
 BF16_MFMA_PEAK_TF = 2500.0
@@ -172,7 +173,7 @@ def main():
 
     kind, M, K, B, H, W, lam = CONFIGS[args.config]
     torch.manual_seed(0)
-    model = nic.JointAutoregressiveHierarchical(M, K).to(dev)
+    model = (nic.HierarchicalMixtureResidual if kind == "hmr" else nic.JointAutoregressiveHierarchical)(M, K).to(dev)
     # Two-stream overlap of the decoder with the latent-side branch (+4 %).  Also on under RCCL data
     # parallelism: rehearsed on one rank with the reducer's hooks and collectives forced
     # (LIC_FORCE_REDUCER=1: 1322 vs 1280 img/s without overlap) -- it needs GPU_MAX_HW_QUEUES set (see the
@@ -237,7 +238,7 @@ def main():
             "value": round(value, 2), "unit": "images/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "bf16" if bf16 else "f32", "data": "synthetic",
-            "config": {"workload": f"cfg{args.config}: JointAutoregressiveHierarchical(M={M},K={K}) "
+            "config": {"workload": f"cfg{args.config}: {type(model).__name__}(M={M},K={K}) "
                                    f"fwd+rd_loss(lambda={lam})+bwd+Adam, {B}x3x{H}x{W} per GPU, "
                                    + ("bf16 storage / fp32 accumulate in the conv+GDN stacks, fp32 elsewhere" if bf16 else "fp32"),
                        "global_batch": world * B, "parallelism": f"dp{world}",
