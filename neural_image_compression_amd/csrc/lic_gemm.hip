@@ -1518,7 +1518,9 @@ static int wg_plan(const lic_wgrad_desc* d, WgPlan* pl) {
             (d->g_ld % 4 == 0) && aligned16(d->g);
   // tile: 128x192 when both operands are wide, else 64-granular
   // 128-row tiles only when they come out full (a half-dead tile parks two of the four waves)
-  pl->TM = (pl->vec && pl->Cm > 64 && (pl->Cm % 128 == 0 || pl->Cm > 256)) ? 2 : 1;
+  // 128-row tiles when they come out full, for wide operands, and for 65..128 channels (one tile, each
+  // operand streamed once: the RGB stem's 76-column weight gradient is pure bandwidth)
+  pl->TM = (pl->vec && pl->Cm > 64 && (pl->Cm % 128 == 0 || pl->Cm > 256 || pl->Cm <= 128)) ? 2 : 1;
   pl->TN = (pl->vec && pl->Cn > 128) ? 3 : (pl->vec && pl->Cn > 64 ? 2 : 1);
   if (pl->TM == 1 && pl->TN == 2) pl->TN = 1;  // instantiated shapes: (2,3) (2,2) (2,1) (1,3) (1,1)
   // 192 x 192 tiles (LDS-DMA kernel only) when both channel counts are multiples of 192: half the
