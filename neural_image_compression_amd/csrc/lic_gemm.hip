@@ -630,10 +630,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
     for (int a = 0; a < TM; ++a)
 #pragma unroll
       for (int b = 0; b < TN; ++b) {
-        __syncthreads();
+        // the patch is wave-private (the K loop ended with a workgroup barrier): wave-level ordering only
+        __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = acc[a][b][r];
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier();
         const int col = n0 + wn0 + b * 32 + c4;
         if (col >= p.Cout) continue;
         f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};

@@ -279,10 +279,10 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
   for (int a = 0; a < TM; ++a)
 #pragma unroll
     for (int b = 0; b < TN; ++b) {
-      __syncthreads();
+      __builtin_amdgcn_wave_barrier();  // wave-private patch
 #pragma unroll
       for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = acc[a][b][r];
-      __syncthreads();
+      __builtin_amdgcn_wave_barrier();
       const int col = n0 + wn0 + b * 32 + c8;
       if (col >= p.Cout) continue;
       float bias8[8];
