@@ -187,7 +187,8 @@ def main():
     broadcast_parameters(model)
     opt = torch.optim.Adam(model.parameters(), lr=1e-4)
     reducer = GradientAllReducer(model.parameters(), overlap=os.environ.get("LIC_REDUCER_NO_OVERLAP") != "1",
-                                 force=force_red, stream_groups=[list(model.decoder.parameters())]) \
+                                 force=force_red, stream_groups=[list(model.decoder.parameters())],
+                                 group_streams=[model.side_stream()] if model.overlap_branches else None) \
         if (world > 1 or force_red) else None
     if os.environ.get("LIC_REDUCER_NOOP") == "1":  # diagnostic: process group up, no gradient exchange
         reducer = None

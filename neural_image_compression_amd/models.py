@@ -98,6 +98,12 @@ class _HyperpriorContextModel(nn.Module):
     # themselves), in forward and -- autograd replays each op on its forward stream -- in backward.
     overlap_branches = True
 
+    def side_stream(self):
+        """the second HIP stream of `overlap_branches` (created on first use)"""
+        if getattr(self, "_side_stream", None) is None:
+            self._side_stream = torch.cuda.Stream()
+        return self._side_stream
+
     def forward(self, x: torch.Tensor, training: bool = True, noise=None):
         """`noise` (test hook, not in the reference): (u_z, u_y) uniform [0,1) tensors used instead
         of torch.rand_like, in the reference's draw order (z first, Models.py:57-58)."""
@@ -105,9 +111,7 @@ class _HyperpriorContextModel(nn.Module):
             out = self.analysis_hyperprior(x, training, noise)
             return {'x_hat': self.decoder(out['y_in']), **out}
         main = torch.cuda.current_stream()
-        if getattr(self, "_side_stream", None) is None:
-            self._side_stream = torch.cuda.Stream()
-        side = self._side_stream
+        side = self.side_stream()
         box = {}
 
         def fork(y_in):

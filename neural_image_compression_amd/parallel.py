@@ -19,7 +19,7 @@ import torch.distributed as dist
 
 class GradientAllReducer:
     def __init__(self, params, process_group=None, bucket_mb: float = 16.0, overlap: bool = True,
-                 force: bool = False, stream_groups=None):
+                 force: bool = False, stream_groups=None, group_streams=None):
         """`force`: run the hooks and collectives even on a single rank (rehearses the data path and its
         stream interplay on a one-GPU box; the result is unchanged: sum of one, mean of one)."""
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
@@ -62,10 +62,26 @@ class GradientAllReducer:
         self._pending = [0] * len(self.buckets)
         self._work = [None] * len(self.buckets)
         self._events = [[] for _ in self.buckets]  # one per gradient: backward may run on several streams
+        # with per-group streams every gradient of a bucket is accumulated on the stream that also runs
+        # the closing hook, so stream order already covers it; otherwise fence each gradient with an event
+        self._fence = not (stream_groups and group_streams)
         self._hooks = []
         if (self.world > 1 or self.force) and overlap:
+            # Registering a hook creates (and pins) the parameter's AccumulateGrad node on the CURRENT
+            # stream.  A group whose gradients are produced on another stream registers under that stream
+            # (`group_streams`), else autograd would synchronise the two streams at every such gradient.
+            stream_of = {}
+            if stream_groups and group_streams:
+                for g, st in zip(stream_groups, group_streams):
+                    for q in g:
+                        stream_of[id(q)] = st
             for i, p in enumerate(self.params):
-                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+                st = stream_of.get(id(p))
+                if st is not None and p.is_cuda:
+                    with torch.cuda.stream(st):
+                        self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+                else:
+                    self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
         self.reset()
 
     def reset(self):
@@ -77,7 +93,7 @@ class GradientAllReducer:
     def _make_hook(self, i):
         def hook(_p):
             b = self._bucket_of[i]
-            if _p.grad is not None and _p.grad.is_cuda:
+            if self._fence and _p.grad is not None and _p.grad.is_cuda:
                 # the model overlaps its decoder and latent branches on two HIP streams, so a bucket's
                 # gradients can come from different streams: fence each one where it was produced
                 ev = torch.cuda.Event()

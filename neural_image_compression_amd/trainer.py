@@ -90,11 +90,14 @@ class Trainer:
         self.reducer = None
         if self.distributed and dist.get_world_size() > 1:
             broadcast_parameters(self.model)
-            self.reducer = GradientAllReducer(self.model.parameters(),
-                                              stream_groups=[list(self.model.decoder.parameters())]
-                                              if hasattr(self.model, "decoder") else None)
             if hasattr(self.model, "overlap_branches") and dist.get_backend() != "nccl":
                 self.model.overlap_branches = False  # ranks time-sharing one GPU (gloo rehearsals) stall with it
+            two = hasattr(self.model, "decoder") and getattr(self.model, "overlap_branches", False) and \
+                next(self.model.parameters()).is_cuda
+            self.reducer = GradientAllReducer(
+                self.model.parameters(),
+                stream_groups=[list(self.model.decoder.parameters())] if hasattr(self.model, "decoder") else None,
+                group_streams=[self.model.side_stream()] if two else None)
         self.writer = writer if writer is not None else (_make_writer(log_dir, self.step) if self.rank == 0 else None)
 
     # -- checkpointing (Trainer.py:52-71) --------------------------------------------------------

@@ -243,3 +243,41 @@ def test_full_capacity_batch_vs_torch_cpu_path(env, K):
         if e > worst[1]:
             worst = (name, e)
     assert worst[1] <= 5e-4, worst
+
+
+@pytest.mark.parametrize("K", [1, 3])
+def test_two_stream_overlap_is_bitwise_neutral(env, K):
+    """The decoder on a second HIP stream (model.overlap_branches) runs the same kernels on the same
+    data: forward outputs, loss and every parameter gradient must equal the single-stream run bit for bit
+    (a missing stream dependency would show up here as a mismatch)."""
+    nic, F_, O, dev = env
+    model = build(nic, nic.JointAutoregressiveHierarchical, 192, K, dev)
+    x = rand_images(16, 256, 256, dev, seed=77)
+    uz = torch.rand(16, 192, 4, 4, device=dev)
+    uy = torch.rand(16, 192, 16, 16, device=dev)
+    runs = {}
+    for ov in (True, False, True):
+        model.overlap_branches = ov
+        model.zero_grad(set_to_none=True)
+        out = model(x, noise=(uz, uy))
+        res = nic.rd_loss(out, x, 0.01)
+        res["loss"].backward()
+        torch.cuda.synchronize()
+        got = [out["x_hat"].detach().clone(), out["logp_y"].detach().clone(), res["loss"].detach().clone()] + \
+              [p.grad.detach().clone() for p in model.parameters()]
+        if ov in runs:
+            for a, b in zip(runs[ov], got):
+                assert torch.equal(a, b)          # run-to-run determinism with the overlap on
+        runs[ov] = got
+    model.overlap_branches = True
+    names = ["x_hat", "logp_y", "loss"] + [n for n, _ in model.named_parameters()]
+    for n, a, b in zip(names, runs[True], runs[False]):
+        if n in ("x_hat", "logp_y", "loss") or n.startswith("decoder.") or n.startswith("entropy_parameters.") \
+                or n.startswith("context_model.") or n.startswith("hyper_decoder."):
+            # everything that does not sit behind the 3-way gradient sum at y_in is bitwise the same
+            assert torch.equal(a, b), f"{n}: two-stream run differs from the single-stream run"
+        else:
+            # dL/dy_in = decoder + context + likelihood terms: autograd adds them in arrival order, which
+            # the second stream changes ((a+b)+c vs (a+c)+b) -- last-bit differences, nothing more
+            scale = float(b.abs().max())
+            assert float((a - b).abs().max()) <= 2e-6 * max(scale, 1e-30), n
