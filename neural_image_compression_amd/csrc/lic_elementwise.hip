@@ -3,6 +3,7 @@
 // likelihoods (forward + backward) and the rate-distortion reductions.
 // All are grid-stride, 16-byte vectorised where the layout allows, wave64 reductions.
 #include "lic_common.h"
+#include "lic_patch.h"
 
 #define EW_BLOCK 256
 static bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -61,8 +62,14 @@ LIC_EXPORT int lic_im2col(const float* x, float* col, int32_t B, int32_t H, int3
   if (!x || !col || B <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || Kpad < kh * kw * C)
     return LIC_ERR_INVALID;
   const long total = (long)B * Ho * Wo * Kpad;
-  hipLaunchKernelGGL(im2col_kernel, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0,
-                     (hipStream_t)stream, x, col, B, H, W, C, Ho, Wo, kh, kw, stride, pad, Kpad);
+  if (Kpad <= LIC_PATCH_MAXK && Kpad % 4 == 0 && total / 4 < 0x7FFFFFFFL && al16(col) && kh < 256 && kw < 256 &&
+      C < 256 && (long)H * W * C < 0x7FFFFFFFL)
+    hipLaunchKernelGGL((im2col_vec_kernel<float, 4>), dim3(ew_grid(total / 4, 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, col, (unsigned)((long)B * Ho * Wo), H, W, C, Ho, Wo, kh, kw, stride, pad,
+                       Kpad);
+  else
+    hipLaunchKernelGGL(im2col_kernel, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0,
+                       (hipStream_t)stream, x, col, B, H, W, C, Ho, Wo, kh, kw, stride, pad, Kpad);
   return lic_check_launch();
 }
 
@@ -101,8 +108,12 @@ LIC_EXPORT int lic_col2im(const float* col, const float* bias, float* out, int32
       Kpad < kh * kw * C)
     return LIC_ERR_INVALID;
   const long total = (long)B * Ho * Wo * C;
-  hipLaunchKernelGGL(col2im_kernel, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0,
-                     (hipStream_t)stream, col, bias, out, B, Hi, Wi, C, Ho, Wo, kh, kw, stride, pad, Kpad);
+  if (total < 0x7FFFFFFFL && (long)B * Hi * Wi < 0x7FFFFFFFL)
+    hipLaunchKernelGGL((col2im_fast_kernel<float>), dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, col,
+                       bias, out, (unsigned)total, Hi, Wi, C, Ho, Wo, kh, kw, stride, pad, Kpad);
+  else
+    hipLaunchKernelGGL(col2im_kernel, dim3(ew_grid(total, EW_BLOCK)), dim3(EW_BLOCK), 0,
+                       (hipStream_t)stream, col, bias, out, B, Hi, Wi, C, Ho, Wo, kh, kw, stride, pad, Kpad);
   return lic_check_launch();
 }
 
@@ -139,6 +150,43 @@ __global__ __launch_bounds__(256) void colsum_stage1(const float* in, long ld, l
     if (cc < C) part[(long)blockIdx.y * C + cc] = s;
   }
 }
+// C == 3 with packed rows (the RGB head's bias gradient over B*H*W pixels): the vector path above needs
+// C % 4 == 0 and the scalar one keeps 16 lanes of a block busy.  Here a lane takes 4 rows = 12 floats as three
+// 16-byte loads; element e of the twelve belongs to channel e % 3.
+__global__ __launch_bounds__(256) void colsum3_stage1(const float* in, long P, float* part, int nchunk) {
+  __shared__ float red[4][3];
+  const long ngroup = P / 4;
+  f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, a2 = a0;
+  for (long g = (long)blockIdx.x * 256 + threadIdx.x; g < ngroup; g += (long)nchunk * 256) {
+    const f32x4* q = reinterpret_cast<const f32x4*>(in + g * 12);
+    a0 += q[0];
+    a1 += q[1];
+    a2 += q[2];
+  }
+  // flat e = 0..11 -> channel e % 3: a0 = (0,1,2,0), a1 = (1,2,0,1), a2 = (2,0,1,2)
+  float c0 = a0[0] + a0[3] + a1[2] + a2[1];
+  float c1 = a0[1] + a1[0] + a1[3] + a2[2];
+  float c2 = a0[2] + a1[1] + a2[0] + a2[3];
+  if (blockIdx.x == 0 && threadIdx.x == 0)
+    for (long r = ngroup * 4; r < P; ++r) {
+      c0 += in[r * 3];
+      c1 += in[r * 3 + 1];
+      c2 += in[r * 3 + 2];
+    }
+  c0 = wave_sum(c0);
+  c1 = wave_sum(c1);
+  c2 = wave_sum(c2);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    red[w][0] = c0;
+    red[w][1] = c1;
+    red[w][2] = c2;
+  }
+  __syncthreads();
+  if (threadIdx.x < 3)
+    part[(long)blockIdx.x * 3 + threadIdx.x] =
+        (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
 // block = 16 columns x 16 chunk lanes (short dependent chains: this stage is pure latency)
 __global__ __launch_bounds__(256) void colsum_stage2(const float* part, int C, int nchunk, float scale,
                                                      float* out) {
@@ -174,8 +222,11 @@ LIC_EXPORT int lic_colsum(const float* in, int64_t ld, int64_t P, int32_t C, flo
   if (workspace_bytes < (size_t)nchunk * C * sizeof(float)) return LIC_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
   const int vec = (C % 4 == 0) && (ld % 4 == 0) && al16(in);
-  hipLaunchKernelGGL(colsum_stage1, dim3((C + 63) / 64, nchunk), dim3(256), 0, s, in, (long)ld, (long)P, C,
-                     (float*)workspace, nchunk, vec);
+  if (C == 3 && ld == 3 && al16(in))
+    hipLaunchKernelGGL(colsum3_stage1, dim3(nchunk), dim3(256), 0, s, in, (long)P, (float*)workspace, nchunk);
+  else
+    hipLaunchKernelGGL(colsum_stage1, dim3((C + 63) / 64, nchunk), dim3(256), 0, s, in, (long)ld, (long)P, C,
+                       (float*)workspace, nchunk, vec);
   int rc = lic_check_launch();
   if (rc != LIC_OK) return rc;
   hipLaunchKernelGGL(colsum_stage2, dim3((C + 15) / 16), dim3(256), 0, s, (const float*)workspace, C,

@@ -1,6 +1,7 @@
 // HBM-bound helpers of the bf16-storage path (BASELINE config 3): patch<->column conversion
 // with bf16 columns, column sums and the GDN dL/dnorm map on bf16 tensors.  fp32 arithmetic inside.
 #include "lic_common.h"
+#include "lic_patch.h"
 
 typedef __bf16 bf16_t;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -34,8 +35,14 @@ LIC_EXPORT int lic_im2col_bf16(const float* x, void* col, int32_t B, int32_t H, 
   if (!x || !col || B <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || Kpad < kh * kw * C)
     return LIC_ERR_INVALID;
   const long total = (long)B * Ho * Wo * Kpad;
-  hipLaunchKernelGGL(im2col_bf16_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
-                     (bf16_t*)col, B, H, W, C, Ho, Wo, kh, kw, stride, pad, Kpad);
+  if (Kpad <= LIC_PATCH_MAXK && Kpad % 8 == 0 && total / 8 < 0x7FFFFFFFL &&
+      (reinterpret_cast<uintptr_t>(col) & 15) == 0 && kh < 256 && kw < 256 && C < 256 && (long)H * W * C < 0x7FFFFFFFL)
+    hipLaunchKernelGGL((im2col_vec_kernel<bf16_t, 8>), dim3(ew_grid(total / 8, 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, (bf16_t*)col, (unsigned)((long)B * Ho * Wo), H, W, C, Ho, Wo, kh, kw,
+                       stride, pad, Kpad);
+  else
+    hipLaunchKernelGGL(im2col_bf16_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       (bf16_t*)col, B, H, W, C, Ho, Wo, kh, kw, stride, pad, Kpad);
   return lic_check_launch();
 }
 
@@ -75,8 +82,12 @@ LIC_EXPORT int lic_col2im_bf16(const void* col, const float* bias, float* out, i
       Kpad < kh * kw * C)
     return LIC_ERR_INVALID;
   const long total = (long)B * Ho * Wo * C;
-  hipLaunchKernelGGL(col2im_bf16_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)col, bias, out, B, Hi, Wi, C, Ho, Wo, kh, kw, stride, pad, Kpad);
+  if (total < 0x7FFFFFFFL && (long)B * Hi * Wi < 0x7FFFFFFFL)
+    hipLaunchKernelGGL((col2im_fast_kernel<bf16_t>), dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)col, bias, out, (unsigned)total, Hi, Wi, C, Ho, Wo, kh, kw, stride, pad, Kpad);
+  else
+    hipLaunchKernelGGL(col2im_bf16_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)col, bias, out, B, Hi, Wi, C, Ho, Wo, kh, kw, stride, pad, Kpad);
   return lic_check_launch();
 }
 

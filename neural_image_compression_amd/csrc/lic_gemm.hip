@@ -755,6 +755,45 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* src, floa
     dst[i] = (k < K && n < N) ? src[tap * s_tap + k * s_k + n * s_n] : 0.0f;
   }
 }
+// The same layout for the strides conv weights have (taps innermost and contiguous, then one of the two
+// channel dims): one workgroup per (16-k chunk, 32-column tile) reads its source block along the contiguous
+// direction into LDS and writes whole packed 2 KiB blocks with 16-byte stores.  RUN_K: for a fixed n the
+// (k, tap) run is contiguous (s_k == taps); else for a fixed k the (n, tap) run is (s_n == taps).
+template <bool RUN_K>
+__global__ __launch_bounds__(256) void pack_weight_tiled_kernel(const float* src, float* dst, int taps, int K,
+                                                                int N, int cpt, int ntile, long s_k, long s_n) {
+  extern __shared__ float pk_st[];  // [taps][16][33]
+  const int cb = blockIdx.x % cpt, tile = blockIdx.x / cpt;
+  const int k0 = cb * IG_BK, n0 = tile * 32;
+  if (RUN_K) {
+    const int run = IG_BK * taps;
+    for (int idx = threadIdx.x; idx < 32 * run; idx += 256) {
+      const int nl = idx / run, j = idx - nl * run;
+      const int kl = j / taps, tap = j - kl * taps;
+      float v = 0.0f;
+      if (k0 + kl < K && n0 + nl < N) v = src[(long)(n0 + nl) * s_n + (long)k0 * taps + j];
+      pk_st[(tap * IG_BK + kl) * 33 + nl] = v;
+    }
+  } else {
+    const int run = 32 * taps;
+    for (int idx = threadIdx.x; idx < IG_BK * run; idx += 256) {
+      const int kl = idx / run, j = idx - kl * run;
+      const int nl = j / taps, tap = j - nl * taps;
+      float v = 0.0f;
+      if (k0 + kl < K && n0 + nl < N) v = src[(long)(k0 + kl) * s_k + (long)n0 * taps + j];
+      pk_st[(tap * IG_BK + kl) * 33 + nl] = v;
+    }
+  }
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < taps * 128; idx += 256) {
+    const int tap = idx >> 7, r = idx & 127, q = r >> 6, lane = r & 63;
+    const int nl = lane & 31, kl = (lane >> 5) * 8 + q * 4;
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = pk_st[(tap * IG_BK + kl + e) * 33 + nl];
+    *reinterpret_cast<f32x4*>(dst + (((long)tap * cpt + cb) * ntile + tile) * 512 + q * 256 + lane * 4) = v;
+  }
+}
 LIC_EXPORT int64_t lic_packed_weight_floats(int32_t taps, int32_t K, int32_t N) {
   if (taps <= 0 || K <= 0 || N <= 0) return 0;
   return (int64_t)taps * ((K + IG_BK - 1) / IG_BK) * (((N + 31) / 32) * 32) * IG_BK;
@@ -764,8 +803,19 @@ LIC_EXPORT int lic_pack_weight(const float* src, float* dst, int32_t taps, int32
   if (!src || !dst || taps <= 0 || K <= 0 || N <= 0) return LIC_ERR_INVALID;
   const int cpt = (K + IG_BK - 1) / IG_BK, Npad = ((N + 31) / 32) * 32;
   const long total = (long)taps * cpt * Npad * IG_BK;
-  hipLaunchKernelGGL(pack_weight_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, src,
-                     dst, taps, K, N, cpt, Npad, (long)s_tap, (long)s_k, (long)s_n);
+  const int ntile = Npad / 32;
+  const size_t lds = (size_t)taps * IG_BK * 33 * sizeof(float);
+  const bool tiled = (taps == 1 || s_tap == 1) && taps <= 30 && aligned16(dst) && (long)cpt * ntile < 0x7FFFFFFFL &&
+                     getenv("LIC_PACK_NO_TILED") == nullptr;
+  if (tiled && s_k == taps)
+    hipLaunchKernelGGL((pack_weight_tiled_kernel<true>), dim3(cpt * ntile), dim3(256), lds, (hipStream_t)stream, src,
+                       dst, taps, K, N, cpt, ntile, (long)s_k, (long)s_n);
+  else if (tiled && s_n == taps)
+    hipLaunchKernelGGL((pack_weight_tiled_kernel<false>), dim3(cpt * ntile), dim3(256), lds, (hipStream_t)stream,
+                       src, dst, taps, K, N, cpt, ntile, (long)s_k, (long)s_n);
+  else
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, src,
+                       dst, taps, K, N, cpt, Npad, (long)s_tap, (long)s_k, (long)s_n);
   return lic_check_launch();
 }
 
@@ -782,6 +832,38 @@ __global__ __launch_bounds__(256) void igemm_finish_kernel(const float* slabs, i
     if (bias) v += bias[c];
     if (leaky) v = v > 0.0f ? v : v * slope;
     out[pix * out_ld + c] = v;
+  }
+}
+// the same, four channels per lane (Cout % 4 == 0, 16-byte aligned rows); slabs are summed in the same
+// order, so both variants give identical bits
+__global__ __launch_bounds__(256) void igemm_finish4_kernel(const float* slabs, int ksplit, unsigned npix,
+                                                            unsigned C4, const float* bias, float* out,
+                                                            long out_ld, int leaky, float slope) {
+  const unsigned total4 = npix * C4;
+  const long total = (long)total4 * 4;
+  for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < total4; i += gridDim.x * 256) {
+    const unsigned pix = i / C4;
+    const unsigned c = (i - pix * C4) * 4;
+    const float* sp = slabs + (long)i * 4;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    int s = 0;
+    for (; s + 4 <= ksplit; s += 4) {  // four loads in flight; summed in slab order
+      const f32x4 a = *reinterpret_cast<const f32x4*>(sp + (long)s * total);
+      const f32x4 b = *reinterpret_cast<const f32x4*>(sp + (long)(s + 1) * total);
+      const f32x4 c2 = *reinterpret_cast<const f32x4*>(sp + (long)(s + 2) * total);
+      const f32x4 d = *reinterpret_cast<const f32x4*>(sp + (long)(s + 3) * total);
+      v += a;
+      v += b;
+      v += c2;
+      v += d;
+    }
+    for (; s < ksplit; ++s) v += *reinterpret_cast<const f32x4*>(sp + (long)s * total);
+    if (bias) v += *reinterpret_cast<const f32x4*>(bias + c);
+    if (leaky) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.0f ? v[e] : v[e] * slope;
+    }
+    *reinterpret_cast<f32x4*>(out + (long)pix * out_ld + c) = v;
   }
 }
 
@@ -1113,9 +1195,16 @@ LIC_EXPORT int lic_igemm(const lic_igemm_desc* d, lic_stream_t stream) {
     int rc2 = lic_check_launch();
     if (rc2 != LIC_OK) return rc2;
     const long npix = (long)d->B * d->Ho * d->Wo;
-    hipLaunchKernelGGL(igemm_finish_kernel, dim3(ew_grid(npix * d->Cout, 256)), dim3(256), 0, s,
-                       (const float*)p.slabs, p.ksplit, npix, d->Cout, d->bias, d->out, (long)d->out_ld,
-                       d->epilogue == LIC_EPI_LEAKY ? 1 : 0, d->slope);
+    const bool v4 = d->Cout % 4 == 0 && d->out_ld % 4 == 0 && aligned16(d->out) && aligned16(p.slabs) &&
+                    (!d->bias || aligned16(d->bias)) && npix * d->Cout < 0x7FFFFFFFL;
+    if (v4)
+      hipLaunchKernelGGL(igemm_finish4_kernel, dim3(ew_grid(npix * d->Cout / 4, 256)), dim3(256), 0, s,
+                         (const float*)p.slabs, p.ksplit, (unsigned)npix, (unsigned)(d->Cout / 4), d->bias, d->out,
+                         (long)d->out_ld, d->epilogue == LIC_EPI_LEAKY ? 1 : 0, d->slope);
+    else
+      hipLaunchKernelGGL(igemm_finish_kernel, dim3(ew_grid(npix * d->Cout, 256)), dim3(256), 0, s,
+                         (const float*)p.slabs, p.ksplit, npix, d->Cout, d->bias, d->out, (long)d->out_ld,
+                         d->epilogue == LIC_EPI_LEAKY ? 1 : 0, d->slope);
   }
   return lic_check_launch();
 }

@@ -498,6 +498,54 @@ def test_model_vs_oracle(env, kind, M, K, B, H, W):
         assert err <= 3e-4 * scale + 1e-7, (pk, err, scale)
 
 
+def _pack_layout_ref(w, taps, K, N, s_tap, s_k, s_n):
+    """numpy restatement of include/lic.h's fp32 packed layout [tap][K/16][Npad/32][2][64][4]"""
+    flat = w.reshape(-1)
+    cpt, ntile = (K + 15) // 16, (N + 31) // 32
+    out = np.zeros((taps, cpt, ntile, 2, 64, 4), np.float32)
+    for tap in range(taps):
+        for k in range(K):
+            for n in range(N):
+                cb, kl = divmod(k, 16)
+                tile, nl = divmod(n, 32)
+                lh, r = divmod(kl, 8)
+                q, e = divmod(r, 4)
+                out[tap, cb, tile, q, lh * 32 + nl, e] = flat[tap * s_tap + k * s_k + n * s_n]
+    return out.reshape(-1)
+
+
+@pytest.mark.parametrize("d0,d1,kh", [(80, 75, 3), (64, 96, 5), (33, 20, 1), (192, 192, 5)])
+def test_pack_weight_tiled_equals_generic(env, d0, d1, kh, monkeypatch):
+    """the LDS-tiled packer (conv-weight strides) writes the same bytes as the generic gather kernel,
+    and both follow the documented layout (ragged K / N zero padded)"""
+    nic, F_, O, dev = env
+    rng = np.random.default_rng(5)
+    w = rng.standard_normal((d0, d1, kh, kh)).astype(np.float32)
+    wd = torch.from_numpy(w).to(dev)
+    taps = kh * kh
+    for dgrad in (False, True):
+        for transposed in (False, True):
+            monkeypatch.delenv("LIC_PACK_NO_TILED", raising=False)
+            a = host(F_._pack_conv_weight(wd, transposed, dgrad))
+            monkeypatch.setenv("LIC_PACK_NO_TILED", "1")
+            b = host(F_._pack_conv_weight(wd, transposed, dgrad))
+            assert np.array_equal(a, b)
+            if d0 * d1 * taps <= 80 * 75 * 9:
+                s_a, s_b = d1 * taps, taps           # strides of dims 0 / 1
+                cin_s, cout_s = (s_a, s_b) if transposed else (s_b, s_a)
+                Kc, Nc = ((d0, d1) if transposed else (d1, d0))   # forward: K = Cin, N = Cout
+                if dgrad:
+                    ref = _pack_layout_ref(w, taps, Nc, Kc, 1, cout_s, cin_s)
+                else:
+                    ref = _pack_layout_ref(w, taps, Kc, Nc, 1, cin_s, cout_s)
+                assert np.array_equal(a, ref)
+    monkeypatch.delenv("LIC_PACK_NO_TILED", raising=False)
+    m = torch.from_numpy(rng.standard_normal((d0, d1)).astype(np.float32)).to(dev)
+    a = host(F_._pack_dense(m))
+    monkeypatch.setenv("LIC_PACK_NO_TILED", "1")
+    assert np.array_equal(a, host(F_._pack_dense(m)))
+
+
 def test_missing_cuda_input_raises(env):
     nic, F_, O, dev = env
     from neural_image_compression_amd._lib import LicError
