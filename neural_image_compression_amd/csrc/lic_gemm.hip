@@ -756,42 +756,49 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* src, floa
   }
 }
 // The same layout for the strides conv weights have (taps innermost and contiguous, then one of the two
-// channel dims): one workgroup per (16-k chunk, 32-column tile) reads its source block along the contiguous
-// direction into LDS and writes whole packed 2 KiB blocks with 16-byte stores.  RUN_K: for a fixed n the
-// (k, tap) run is contiguous (s_k == taps); else for a fixed k the (n, tap) run is (s_n == taps).
+// channel dims): one workgroup per (16-k chunk, 8 columns) reads its source block along the contiguous
+// direction into LDS (four loads in flight per lane) and writes 128-byte pieces of the packed blocks with
+// 16-byte stores.  RUN_K: for a fixed n the (k, tap) run is contiguous (s_k == taps); else for a fixed k the
+// (n, tap) run is (s_n == taps).
+#define PK_NS 8
 template <bool RUN_K>
 __global__ __launch_bounds__(256) void pack_weight_tiled_kernel(const float* src, float* dst, int taps, int K,
                                                                 int N, int cpt, int ntile, long s_k, long s_n) {
-  extern __shared__ float pk_st[];  // [taps][16][33]
-  const int cb = blockIdx.x % cpt, tile = blockIdx.x / cpt;
-  const int k0 = cb * IG_BK, n0 = tile * 32;
-  if (RUN_K) {
-    const int run = IG_BK * taps;
-    for (int idx = threadIdx.x; idx < 32 * run; idx += 256) {
-      const int nl = idx / run, j = idx - nl * run;
-      const int kl = j / taps, tap = j - kl * taps;
-      float v = 0.0f;
-      if (k0 + kl < K && n0 + nl < N) v = src[(long)(n0 + nl) * s_n + (long)k0 * taps + j];
-      pk_st[(tap * IG_BK + kl) * 33 + nl] = v;
+  extern __shared__ float pk_st[];  // [taps][16][PK_NS + 1]
+  const int cb = blockIdx.x % cpt, nb = blockIdx.x / cpt;  // nb: 8-column block
+  const int k0 = cb * IG_BK, n0 = nb * PK_NS;
+  const int run = (RUN_K ? IG_BK : PK_NS) * taps, total = IG_BK * PK_NS * taps;
+  for (int base = threadIdx.x; base < total; base += 4 * 256) {
+    float v[4];
+    int slot[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = base + u * 256;
+      v[u] = 0.0f;
+      slot[u] = -1;
+      if (idx < total) {
+        const int o = idx / run, j = idx - o * run;  // o: outer index (n if RUN_K else k)
+        const int i = j / taps, tap = j - i * taps;  // i: inner index (k if RUN_K else n)
+        const int kl = RUN_K ? i : o, nl = RUN_K ? o : i;
+        slot[u] = (tap * IG_BK + kl) * (PK_NS + 1) + nl;
+        if (k0 + kl < K && n0 + nl < N)
+          v[u] = RUN_K ? src[(long)(n0 + nl) * s_n + (long)k0 * taps + j]
+                       : src[(long)(k0 + kl) * s_k + (long)n0 * taps + j];
+      }
     }
-  } else {
-    const int run = 32 * taps;
-    for (int idx = threadIdx.x; idx < IG_BK * run; idx += 256) {
-      const int kl = idx / run, j = idx - kl * run;
-      const int nl = j / taps, tap = j - nl * taps;
-      float v = 0.0f;
-      if (k0 + kl < K && n0 + nl < N) v = src[(long)(k0 + kl) * s_k + (long)n0 * taps + j];
-      pk_st[(tap * IG_BK + kl) * 33 + nl] = v;
-    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      if (slot[u] >= 0) pk_st[slot[u]] = v[u];
   }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < taps * 128; idx += 256) {
-    const int tap = idx >> 7, r = idx & 127, q = r >> 6, lane = r & 63;
-    const int nl = lane & 31, kl = (lane >> 5) * 8 + q * 4;
-    f32x4 v;
+  const int tile = n0 >> 5, nin = n0 & 31;
+  for (int idx = threadIdx.x; idx < taps * 32; idx += 256) {
+    const int tap = idx >> 5, r = idx & 31, q = r >> 4, lh = (r >> 3) & 1, nl = r & 7;
+    const int kl = lh * 8 + q * 4, lane = lh * 32 + nin + nl;
+    f32x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) v[e] = pk_st[(tap * IG_BK + kl + e) * 33 + nl];
-    *reinterpret_cast<f32x4*>(dst + (((long)tap * cpt + cb) * ntile + tile) * 512 + q * 256 + lane * 4) = v;
+    for (int e = 0; e < 4; ++e) o[e] = pk_st[(tap * IG_BK + kl + e) * (PK_NS + 1) + nl];
+    *reinterpret_cast<f32x4*>(dst + (((long)tap * cpt + cb) * ntile + tile) * 512 + q * 256 + lane * 4) = o;
   }
 }
 LIC_EXPORT int64_t lic_packed_weight_floats(int32_t taps, int32_t K, int32_t N) {
@@ -804,14 +811,15 @@ LIC_EXPORT int lic_pack_weight(const float* src, float* dst, int32_t taps, int32
   const int cpt = (K + IG_BK - 1) / IG_BK, Npad = ((N + 31) / 32) * 32;
   const long total = (long)taps * cpt * Npad * IG_BK;
   const int ntile = Npad / 32;
-  const size_t lds = (size_t)taps * IG_BK * 33 * sizeof(float);
-  const bool tiled = (taps == 1 || s_tap == 1) && taps <= 30 && aligned16(dst) && (long)cpt * ntile < 0x7FFFFFFFL &&
+  const size_t lds = (size_t)taps * IG_BK * (PK_NS + 1) * sizeof(float);
+  const int nblk = Npad / PK_NS;  // Npad is a multiple of 32
+  const bool tiled = s_tap == 1 && taps >= 4 && taps <= 64 && aligned16(dst) && (long)cpt * nblk < 0x7FFFFFFFL &&
                      getenv("LIC_PACK_NO_TILED") == nullptr;
   if (tiled && s_k == taps)
-    hipLaunchKernelGGL((pack_weight_tiled_kernel<true>), dim3(cpt * ntile), dim3(256), lds, (hipStream_t)stream, src,
+    hipLaunchKernelGGL((pack_weight_tiled_kernel<true>), dim3(cpt * nblk), dim3(256), lds, (hipStream_t)stream, src,
                        dst, taps, K, N, cpt, ntile, (long)s_k, (long)s_n);
   else if (tiled && s_n == taps)
-    hipLaunchKernelGGL((pack_weight_tiled_kernel<false>), dim3(cpt * ntile), dim3(256), lds, (hipStream_t)stream,
+    hipLaunchKernelGGL((pack_weight_tiled_kernel<false>), dim3(cpt * nblk), dim3(256), lds, (hipStream_t)stream,
                        src, dst, taps, K, N, cpt, ntile, (long)s_k, (long)s_n);
   else
     hipLaunchKernelGGL(pack_weight_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, src,

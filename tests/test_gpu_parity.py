@@ -468,9 +468,13 @@ def test_model_golden(env, golden_dir, name):
 
 
 @pytest.mark.parametrize("kind,M,K,B,H,W", [("5x5", 32, 1, 2, 64, 128), ("5x5", 48, 3, 1, 64, 64),
-                                            ("3x3", 32, 3, 1, 64, 64)])
+                                            ("3x3", 32, 3, 1, 64, 64),
+                                            # ragged: channel counts off the 16/32-wide tiles (scalar-load
+                                            # variant, zero-padded K and N), odd batch, tall image
+                                            ("5x5", 20, 2, 3, 128, 64), ("5x5", 7, 1, 1, 64, 64),
+                                            ("3x3", 12, 1, 2, 64, 128)])
 def test_model_vs_oracle(env, kind, M, K, B, H, W):
-    """Bigger channel counts (vector-load fast path, multi-tile N) against the oracle."""
+    """Bigger channel counts (vector-load fast path, multi-tile N) and ragged shapes against the oracle."""
     nic, F_, O, dev = env
     cls = nic.JointAutoregressiveHierarchical if kind == "5x5" else nic.HierarchicalMixtureResidual
     model = cls(M, K)

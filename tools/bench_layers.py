@@ -92,6 +92,15 @@ def main():
             w = torch.randn(co, ci, k, k, device=dev, requires_grad=True)
             b = torch.randn(co, device=dev, requires_grad=True)
             run(tag, lambda x, w, b: F_.conv2d(x, w, b, s, k // 2, True), nhwc(B, ci, hi, hi), w, b)
+    for (ci, co, hi, tag) in ((M, M, 4, "hdec convT5 4->8"), (M, 288, 8, "hdec convT5 8->16")):
+        if want(tag):
+            w = torch.randn(ci, co, 5, 5, device=dev, requires_grad=True)
+            b = torch.randn(co, device=dev, requires_grad=True)
+            run(tag, lambda x, w, b: F_.conv_transpose2d(x, w, b, 2, 2, 1, True), nhwc(B, ci, hi, hi), w, b)
+    if want("hdec conv3x3"):
+        w = torch.randn(2 * M, 288, 3, 3, device=dev, requires_grad=True)
+        b = torch.randn(2 * M, device=dev, requires_grad=True)
+        run("hdec conv3x3 288->384", lambda x, w, b: F_.conv2d(x, w, b, 1, 1), nhwc(B, 288, 16, 16), w, b)
 
 
 if __name__ == "__main__":
