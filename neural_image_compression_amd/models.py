@@ -2,6 +2,8 @@
 `ScalableImageCoding` (Models.py:208-338) is out of scope: its forward raises upstream."""
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -101,7 +103,10 @@ class _HyperpriorContextModel(nn.Module):
     def side_stream(self):
         """the second HIP stream of `overlap_branches` (created on first use)"""
         if getattr(self, "_side_stream", None) is None:
-            self._side_stream = torch.cuda.Stream()
+            # High priority: the decoder chain is the critical path of the overlapped region, the latent-side
+            # launches on the main stream fill what it leaves (+0.6 % step, and the big decoder launches keep
+            # ~5 % more of their stand-alone speed).  LIC_SIDE_PRIORITY=0 for the A/B.
+            self._side_stream = torch.cuda.Stream(priority=int(os.environ.get("LIC_SIDE_PRIORITY", "-1")))
         return self._side_stream
 
     def forward(self, x: torch.Tensor, training: bool = True, noise=None):
