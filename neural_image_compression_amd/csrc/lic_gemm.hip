@@ -761,34 +761,69 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float* src, floa
 // 16-byte stores.  RUN_K: for a fixed n the (k, tap) run is contiguous (s_k == taps); else for a fixed k the
 // (n, tap) run is (s_n == taps).
 #define PK_NS 8
-template <bool RUN_K>
+// V4: whole blocks (K % 16 == 0, N % 8 == 0) whose runs are 16-byte aligned are read with 16-byte loads --
+// right after the optimizer step the weights are cold, and 4-byte gathers keep too few bytes in flight.
+template <bool RUN_K, bool V4>
 __global__ __launch_bounds__(256) void pack_weight_tiled_kernel(const float* src, float* dst, int taps, int K,
                                                                 int N, int cpt, int ntile, long s_k, long s_n) {
   extern __shared__ float pk_st[];  // [taps][16][PK_NS + 1]
   const int cb = blockIdx.x % cpt, nb = blockIdx.x / cpt;  // nb: 8-column block
   const int k0 = cb * IG_BK, n0 = nb * PK_NS;
   const int run = (RUN_K ? IG_BK : PK_NS) * taps, total = IG_BK * PK_NS * taps;
-  for (int base = threadIdx.x; base < total; base += 4 * 256) {
-    float v[4];
-    int slot[4];
+  if (V4) {
+    for (int base = threadIdx.x; base < total / 4; base += 4 * 256) {
+      f32x4 v[4];
+      int jj[4], oo[4];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int idx = base + u * 256;
-      v[u] = 0.0f;
-      slot[u] = -1;
-      if (idx < total) {
-        const int o = idx / run, j = idx - o * run;  // o: outer index (n if RUN_K else k)
-        const int i = j / taps, tap = j - i * taps;  // i: inner index (k if RUN_K else n)
-        const int kl = RUN_K ? i : o, nl = RUN_K ? o : i;
-        slot[u] = (tap * IG_BK + kl) * (PK_NS + 1) + nl;
-        if (k0 + kl < K && n0 + nl < N)
-          v[u] = RUN_K ? src[(long)(n0 + nl) * s_n + (long)k0 * taps + j]
-                       : src[(long)(k0 + kl) * s_k + (long)n0 * taps + j];
+      for (int u = 0; u < 4; ++u) {
+        const int idx = (base + u * 256) * 4;
+        oo[u] = -1;
+        if (idx < total) {
+          const int o = idx / run, j = idx - o * run;
+          oo[u] = o;
+          jj[u] = j;
+          v[u] = *reinterpret_cast<const f32x4*>(RUN_K ? src + (long)(n0 + o) * s_n + (long)k0 * taps + j
+                                                       : src + (long)(k0 + o) * s_k + (long)n0 * taps + j);
+        }
       }
-    }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
-      if (slot[u] >= 0) pk_st[slot[u]] = v[u];
+      for (int u = 0; u < 4; ++u)
+        if (oo[u] >= 0) {
+          int i = jj[u] / taps, tap = jj[u] - i * taps;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int kl = RUN_K ? i : oo[u], nl = RUN_K ? oo[u] : i;
+            pk_st[(tap * IG_BK + kl) * (PK_NS + 1) + nl] = v[u][e];
+            if (++tap == taps) {
+              tap = 0;
+              ++i;
+            }
+          }
+        }
+    }
+  } else {
+    for (int base = threadIdx.x; base < total; base += 4 * 256) {
+      float v[4];
+      int slot[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int idx = base + u * 256;
+        v[u] = 0.0f;
+        slot[u] = -1;
+        if (idx < total) {
+          const int o = idx / run, j = idx - o * run;  // o: outer index (n if RUN_K else k)
+          const int i = j / taps, tap = j - i * taps;  // i: inner index (k if RUN_K else n)
+          const int kl = RUN_K ? i : o, nl = RUN_K ? o : i;
+          slot[u] = (tap * IG_BK + kl) * (PK_NS + 1) + nl;
+          if (k0 + kl < K && n0 + nl < N)
+            v[u] = RUN_K ? src[(long)(n0 + nl) * s_n + (long)k0 * taps + j]
+                         : src[(long)(k0 + kl) * s_k + (long)n0 * taps + j];
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (slot[u] >= 0) pk_st[slot[u]] = v[u];
+    }
   }
   __syncthreads();
   const int tile = n0 >> 5, nin = n0 & 31;
@@ -815,12 +850,19 @@ LIC_EXPORT int lic_pack_weight(const float* src, float* dst, int32_t taps, int32
   const int nblk = Npad / PK_NS;  // Npad is a multiple of 32
   const bool tiled = s_tap == 1 && taps >= 4 && taps <= 64 && aligned16(dst) && (long)cpt * nblk < 0x7FFFFFFFL &&
                      getenv("LIC_PACK_NO_TILED") == nullptr;
-  if (tiled && s_k == taps)
-    hipLaunchKernelGGL((pack_weight_tiled_kernel<true>), dim3(cpt * nblk), dim3(256), lds, (hipStream_t)stream, src,
-                       dst, taps, K, N, cpt, ntile, (long)s_k, (long)s_n);
-  else if (tiled && s_n == taps)
-    hipLaunchKernelGGL((pack_weight_tiled_kernel<false>), dim3(cpt * nblk), dim3(256), lds, (hipStream_t)stream,
-                       src, dst, taps, K, N, cpt, ntile, (long)s_k, (long)s_n);
+  // 16-byte source loads: whole blocks, every (outer index, block) run starting on a 16-byte boundary
+  const bool v4 = tiled && K % IG_BK == 0 && N % PK_NS == 0 && aligned16(src) && (s_k == taps ? s_n : s_k) % 4 == 0;
+#define LIC_PACK_LAUNCH(rk, v)                                                                                  \
+  hipLaunchKernelGGL((pack_weight_tiled_kernel<rk, v>), dim3(cpt * nblk), dim3(256), lds, (hipStream_t)stream, src, \
+                     dst, taps, K, N, cpt, ntile, (long)s_k, (long)s_n)
+  if (tiled && s_k == taps) {
+    if (v4) LIC_PACK_LAUNCH(true, true);
+    else LIC_PACK_LAUNCH(true, false);
+  } else if (tiled && s_n == taps) {
+    if (v4) LIC_PACK_LAUNCH(false, true);
+    else LIC_PACK_LAUNCH(false, false);
+  }
+#undef LIC_PACK_LAUNCH
   else
     hipLaunchKernelGGL(pack_weight_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, src,
                        dst, taps, K, N, cpt, Npad, (long)s_tap, (long)s_k, (long)s_n);
