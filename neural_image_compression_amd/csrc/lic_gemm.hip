@@ -770,7 +770,9 @@ __global__ __launch_bounds__(256) void pack_weight_tiled_kernel(const float* src
   const int cb = blockIdx.x % cpt, nb = blockIdx.x / cpt;  // nb: 8-column block
   const int k0 = cb * IG_BK, n0 = nb * PK_NS;
   const int run = (RUN_K ? IG_BK : PK_NS) * taps, total = IG_BK * PK_NS * taps;
-  if (V4) {
+  if (V4 && n0 >= N) {  // a whole block of the zero padding between N and ceil32(N) (N % 8 == 0 here)
+    for (int i = threadIdx.x; i < taps * IG_BK * (PK_NS + 1); i += 256) pk_st[i] = 0.0f;
+  } else if (V4) {
     for (int base = threadIdx.x; base < total / 4; base += 4 * 256) {
       f32x4 v[4];
       int jj[4], oo[4];

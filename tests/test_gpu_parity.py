@@ -518,7 +518,7 @@ def _pack_layout_ref(w, taps, K, N, s_tap, s_k, s_n):
     return out.reshape(-1)
 
 
-@pytest.mark.parametrize("d0,d1,kh", [(80, 75, 3), (64, 96, 5), (33, 20, 1), (192, 192, 5)])
+@pytest.mark.parametrize("d0,d1,kh", [(80, 75, 3), (64, 96, 5), (33, 20, 1), (192, 192, 5), (48, 48, 5), (16, 40, 3)])
 def test_pack_weight_tiled_equals_generic(env, d0, d1, kh, monkeypatch):
     """the LDS-tiled packer (conv-weight strides) writes the same bytes as the generic gather kernel,
     and both follow the documented layout (ragged K / N zero padded)"""
