@@ -45,15 +45,24 @@ class CompressionEvaluator:
         out["MS-SSIM(Y)"] = self._ms_ssim(Y_recon, Y_orig, data_range=1.0, size_average=True).item()
         return out
 
-    def evaluate(self, rd_loss_fn):
+    def evaluate(self, rd_loss_fn, coded: bool = False):
+        """`coded=True` (not in the reference, which has no entropy coder) also writes every batch through
+        `codec.ContextCodec` and reports the size of the actual bitstream as 'BPP(coded)' next to the
+        estimated -log2 p rates."""
         self.model.eval()
-        total_metrics, bpp_values, bpp_y_values, bpp_z_values = [], [], [], []
+        total_metrics, bpp_values, bpp_y_values, bpp_z_values, bpp_coded = [], [], [], [], []
         imgs_list, recon_list = [], []
+        codec = None
+        if coded:
+            from .codec import ContextCodec
+            codec = ContextCodec(self.model)
         with torch.no_grad():
             for imgs in self.dataloader:
                 imgs = imgs.to(self.device)
                 out = self.model(imgs, training=False)
                 results = rd_loss_fn(out, imgs, self.lambda_val)
+                if codec is not None:
+                    bpp_coded.append(codec.compress(imgs)["bpp_coded"])
                 bpp_values.append(results["bpp_total"])
                 bpp_y_values.append(results["bpp_y"])
                 bpp_z_values.append(results["bpp_z"])
@@ -65,6 +74,8 @@ class CompressionEvaluator:
         avg_metrics['BPP(y)'] = float(np.mean(bpp_y_values))
         avg_metrics['BPP(z)'] = float(np.mean(bpp_z_values))
         avg_metrics['BPP(total)'] = float(np.mean(bpp_values))
+        if bpp_coded:
+            avg_metrics['BPP(coded)'] = float(np.mean(bpp_coded))
         print("\n--- Evaluation Results ---")
         for k, v in avg_metrics.items():
             print(f"{k}: {v:.6f}")

@@ -182,3 +182,26 @@ def test_context_codec_full_round_trip(codec, K, B, H, W):
     assert torch.equal(dec["x_hat"], ref["x_hat"])
     npix = B * H * W
     assert abs(enc["bpp_coded"] - enc["bpp_est"]) <= 0.02 * enc["bpp_est"] + (64.0 * (B + 1)) / npix
+
+
+@pytest.mark.gpu
+def test_evaluator_reports_coded_bpp(codec, tmp_path):
+    """CompressionEvaluator.evaluate(coded=True): the bitstream size sits next to the estimated rates"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    import neural_image_compression_amd as nic
+    from neural_image_compression_amd.evaluator import CompressionEvaluator
+    import golden_recipe as R
+    model = nic.JointAutoregressiveHierarchical(32, 3)
+    st = R.make_state([(k, tuple(v.shape)) for k, v in model.state_dict().items()], 61)
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
+    model = model.cuda()
+    # Kodak-like minimum for MS-SSIM (side > 160)
+    batches = [torch.from_numpy(R.make_image(1, 192, 256, 62 + i)).contiguous(memory_format=torch.channels_last)
+               for i in range(2)]
+    ev = CompressionEvaluator(model, batches, torch.device("cuda:0"), 0.01, save_dir=str(tmp_path))
+    m, _, _ = ev.evaluate(nic.rd_loss, coded=True)
+    assert "BPP(coded)" in m and m["BPP(coded)"] > 0
+    assert abs(m["BPP(coded)"] - m["BPP(total)"]) <= 0.02 * m["BPP(total)"] + 128.0 / (192 * 256)
+    m2, _, _ = ev.evaluate(nic.rd_loss)
+    assert "BPP(coded)" not in m2 and m2["BPP(total)"] == m["BPP(total)"]
