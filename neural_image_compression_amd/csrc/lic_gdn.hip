@@ -49,6 +49,25 @@ __global__ __launch_bounds__(256) void gdn_kernel(const GdnParams p) {
   const bool inv = p.inverse != 0;
 
   // ---- one sweep over the tile: whole rows, 16 bytes per lane ------------------------------------
+  if (MODE == 0) {
+    // forward: all SLOTS loads in flight at once (one HBM round trip per tile instead of SLOTS / 4: the
+    // sweep was 28 % of the waves' time in s_waitcnt, SQ_WAIT_ANY)
+    f32x4 a[SLOTS];
+#pragma unroll
+    for (int u = 0; u < SLOTS; ++u) {
+      const int idx = u * 256 + tid;
+      const int row = idx / (C / 4), c4 = (idx - row * (C / 4)) * 4;
+      const bool ok = m0 + row < p.P;
+      a[u] = *reinterpret_cast<const f32x4*>(p.x + (ok ? (m0 + row) * C + c4 : 0L));
+      if (!ok) a[u] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int u = 0; u < SLOTS; ++u) {
+      const int idx = u * 256 + tid;
+      const int row = idx / (C / 4), c4 = (idx - row * (C / 4)) * 4;
+      *reinterpret_cast<f32x4*>(&smem[row * LDX + c4]) = a[u];
+    }
+  } else {
 #pragma unroll
   for (int s0 = 0; s0 < SLOTS; s0 += 4) {
     f32x4 a[4], b[4], c[4];
@@ -60,28 +79,25 @@ __global__ __launch_bounds__(256) void gdn_kernel(const GdnParams p) {
       ok[u] = m0 + row < p.P;
       const long off = ok[u] ? (m0 + row) * C + c4 : 0L;
       a[u] = *reinterpret_cast<const f32x4*>(p.x + off);
-      if (MODE == 1) {
-        b[u] = *reinterpret_cast<const f32x4*>(p.g + off);
-        c[u] = *reinterpret_cast<const f32x4*>(p.norm + off);
-      }
+      b[u] = *reinterpret_cast<const f32x4*>(p.g + off);
+      c[u] = *reinterpret_cast<const f32x4*>(p.norm + off);
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const int idx = (s0 + u) * 256 + tid;
       const int row = idx / (C / 4), c4 = (idx - row * (C / 4)) * 4;
-      f32x4 v = a[u];
-      if (MODE == 1) {
+      f32x4 v;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float rs = __builtin_amdgcn_rsqf(c[u][e]);  // as lic_gdn_dnorm
-          const float gx = b[u][e] * a[u][e];
-          v[e] = inv ? 0.5f * gx * rs : -0.5f * gx * rs * (rs * rs);
-        }
-        if (ok[u]) *reinterpret_cast<f32x4*>(p.out2 + (m0 + row) * C + c4) = v;
+      for (int e = 0; e < 4; ++e) {
+        const float rs = __builtin_amdgcn_rsqf(c[u][e]);  // as lic_gdn_dnorm
+        const float gx = b[u][e] * a[u][e];
+        v[e] = inv ? 0.5f * gx * rs : -0.5f * gx * rs * (rs * rs);
       }
+      if (ok[u]) *reinterpret_cast<f32x4*>(p.out2 + (m0 + row) * C + c4) = v;
       if (!ok[u]) v = f32x4{0.f, 0.f, 0.f, 0.f};
       *reinterpret_cast<f32x4*>(&smem[row * LDX + c4]) = v;
     }
+  }
   }
   __syncthreads();
   if (MODE == 1 && p.cs_t && tid < C) {  // column sums of the t tile (rows past P are zero), fixed order
