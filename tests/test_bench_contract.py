@@ -1,0 +1,82 @@
+"""bench.py's output contract: one JSON line with the driver's keys plus `roofline` and `cpu_baseline`.
+CPU: the newest committed line under profiles/ has every key with a sane type, bench.py refuses to run
+without a GPU (no CPU fallback).  GPU: a short live run prints a conforming line."""
+import glob
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CONTRACT = {"metric": str, "value": (int, float), "unit": str, "n_gpus": int, "steps": int, "warmup": int,
+            "ms_per_step": (int, float), "higher_is_better": bool, "scaling": str, "dtype": str, "data": str,
+            "config": dict}
+ROOFLINE = {"bound": str, "achieved": (int, float), "peak": (int, float), "unit": str, "frac": (int, float)}
+CPU_BASELINE = {"value": (int, float), "unit": str, "cores": int, "kind": str, "sample": str}
+
+
+def check_line(d, want_cpu):
+    for k, t in CONTRACT.items():
+        assert k in d and isinstance(d[k], t), k
+    assert "vs_baseline" in d and d["vs_baseline"] is None      # BASELINE.md publishes no number for this metric
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["data"] == "synthetic"
+    assert d["unit"] == "images/s" and d["value"] > 0
+    assert "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - d["config"]["global_batch"] / d["ms_per_step"] * 1e3) <= 0.01 * d["value"]
+    r = d["roofline"]
+    for k, t in ROOFLINE.items():
+        assert k in r and isinstance(r[k], t), k
+    assert r["bound"] in ("hbm", "mfma") and "traffic" in r
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    if want_cpu:
+        c = d["cpu_baseline"]
+        for k, t in CPU_BASELINE.items():
+            assert k in c and isinstance(c[k], t), k
+        assert c["kind"] in ("reference", "port") and c["cores"] >= 1
+
+
+def test_committed_bench_line_follows_the_contract():
+    lines = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_bench_line.json")))
+    assert lines, "no bench line committed under profiles/"
+    d = json.loads(open(lines[-1]).read().strip().splitlines()[-1])
+    check_line(d, want_cpu=True)
+    assert d["n_gpus"] == 1 and d["dtype"] == "f32" and "cfg2" in d["config"]["workload"]
+    # the rocprofv3 summary of the same command is committed next to it and names the same kernel
+    stats = lines[-1].replace("_bench_line.json", "_kernel_stats_bench_cfg2.csv")
+    assert os.path.exists(stats) and d["roofline"]["kernel"] in open(stats).read()
+
+
+def test_bench_refuses_to_run_without_a_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, timeout=300)
+    assert p.returncode != 0 and "no CPU fallback" in (p.stderr + p.stdout)
+
+
+def test_bench_configs_cover_baseline_json():
+    sys.path.insert(0, ROOT)
+    import bench
+    base = json.load(open(os.path.join(ROOT, "BASELINE.json")))
+    assert len(base["configs"]) == 5
+    for k in ("2", "3", "4", "5"):
+        assert k in bench.CONFIGS
+    kind, M, K, B, H, W, lam = bench.CONFIGS["2"]
+    assert (kind, M, K, B, H, W) == ("jah", 192, 1, 32, 256, 256)
+
+
+@pytest.mark.gpu
+def test_live_bench_line():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "2",
+                        "--no-cpu-baseline", "--no-analysis-fwd"], capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads(p.stdout.strip().splitlines()[-1])
+    check_line(d, want_cpu=False)
+    assert d["steps"] == 3 and d["warmup"] == 2 and d["n_gpus"] == 1
