@@ -1067,6 +1067,14 @@ static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& 
     }
   BM = cand[best][0];
   TN = cand[best][1];
+  if (const char* e = getenv("LIC_IGEMM_FORCE_TILE")) {  // tuning aid: "bm,tn"
+    int fb = 0, ft = 0;
+    if (sscanf(e, "%d,%d", &fb, &ft) == 2 && (fb == 64 || fb == 128) && ft >= 1 && ft <= 3 && p.vec &&
+        p.Npad % (64 * ft) == 0) {
+      BM = fb;
+      TN = ft;
+    }
+  }
   // One N tile spanning every channel, 64 rows.  (A 128-row fused variant was built and measured:
   // all workgroups of a launch reach their epilogue together, so the pool is not hidden behind other
   // workgroups' K loops, and the big layers came out 15-20 % slower than conv + a separate GDN
@@ -1106,10 +1114,11 @@ static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& 
   // The split factor depends only on per-image geometry (never on the batch size), so an image's
   // result does not depend on which batch it is computed in (bitwise batch-split invariance).
   const long t_img = (((long)d->Ho * d->Wo + 63) / 64) * ((p.Npad + 63) / 64);
-  if (simple_epi && !fuse && d->workspace && t_img < 40 && max_chunks >= 16) {
+  if (simple_epi && !fuse && d->workspace && (t_img < 40 || getenv("LIC_IGEMM_FORCE_SPLIT")) && max_chunks >= 16) {
     long S = (40 + t_img - 1) / t_img;
     if (S > max_chunks / 8) S = max_chunks / 8;  // at least 8 chunks per split
     if (S > 32) S = 32;
+    if (const char* e = getenv("LIC_IGEMM_FORCE_SPLIT")) S = atoi(e);  // tuning aid
     if (S > 1) {
       p.cps = (int)((max_chunks + S - 1) / S);
       p.ksplit = (max_chunks + p.cps - 1) / p.cps;
