@@ -235,13 +235,31 @@ class ContextCodec:
         cols = [w[:, :, r, s] for (r, s) in self.taps]                         # each [2M, M]
         return torch.cat(cols, dim=1).reshape(w.shape[0], -1, 1, 1).contiguous(), mc.bias.detach()
 
-    def _params_at(self, windows: torch.Tensor, psi_px: torch.Tensor, wg, bg):
-        """windows [N, 12M, 1, 1], psi_px [N, 2M, 1, 1] -> (center [N, M], tables [N*M, S+1] on the host)"""
+    def _prepack(self):
+        """The four per-pixel layers (context GEMM + the 1x1 MLP) with their weights packed ONCE: the decoder
+        runs them h*w times; packing per call moved ~10 MB per latent pixel."""
         m = self.model
-        phi = F_.conv2d(windows, wg, bg, 1, 0)
-        act = m.entropy_parameters.packed(torch.cat([phi, psi_px], dim=1))
-        center, tables = gmm_tables(act, m.M, m.K, self.y_W)
-        return center, tables
+        wg, bg = self._ctx_weight()
+        net = m.entropy_parameters.net
+        convs = [net[0], net[2], net[4]]
+        slopes = [net[1].negative_slope, net[3].negative_slope]
+        layers = [(F_.pack_conv_weight(wg), bg, wg.shape[0], False, 0.01)]
+        for i, c in enumerate(convs):
+            if c.kernel_size != (1, 1):
+                raise CodecError("entropy-parameter layers are expected to be 1x1 convolutions")
+            layers.append((F_.pack_conv_weight(c.weight), None if c.bias is None else c.bias.detach(), c.out_channels,
+                           i < 2, slopes[i] if i < 2 else 0.01))
+        return layers
+
+    def _params_at(self, windows: torch.Tensor, psi_px: torch.Tensor, layers):
+        """windows [N, 12M, 1, 1], psi_px [N, 2M, 1, 1] -> (center [N, M], tables [N*M, S+1]) on the device"""
+        m = self.model
+        wp, b, co, _, _ = layers[0]
+        x = torch.cat([F_.conv2d_prepacked(windows, wp, b, co, 1), psi_px], dim=1)
+        for wp, b, co, leaky, slope in layers[1:]:
+            x = F_.conv2d_prepacked(x, wp, b, co, 1, leaky=leaky, slope=slope)
+        act = F_.entropy_params_activation(x, m.M, m.K)
+        return gmm_tables(act, m.M, m.K, self.y_W)
 
     def _windows_all(self, y_hat: torch.Tensor) -> torch.Tensor:
         """[B, M, h, w] -> [B*h*w, 12M, 1, 1]: the live taps of every pixel (zeros outside the image)"""
@@ -262,9 +280,8 @@ class ContextCodec:
         z_idx = (z_in.permute(0, 2, 3, 1).contiguous().round().to(torch.int32) - self.z_lo).cpu().numpy().ravel()
         z_bytes = rc_encode(zt, z_idx, np.tile(np.arange(M, dtype=np.int32), z_idx.size // M))
         psi = m.hyper_decoder(z_in)
-        wg, bg = self._ctx_weight()
         psi_px = psi.permute(0, 2, 3, 1).reshape(B * h * w, -1, 1, 1).contiguous()
-        center, tables = self._params_at(self._windows_all(y_in), psi_px, wg, bg)
+        center, tables = self._params_at(self._windows_all(y_in), psi_px, self._prepack())
         y_sym = y_in.permute(0, 2, 3, 1).reshape(B * h * w, M).round().to(torch.int32)
         idx = (y_sym - center + self.y_W).cpu().numpy().reshape(B, h * w * M)
         tabs = tables.cpu().numpy().view(np.uint32).reshape(B, h * w * M, -1)
@@ -283,24 +300,52 @@ class ContextCodec:
         z_hat = LatentCodec(m, self.z_lo, self.z_S, self.y_W).decompress_z(strings["z"], z_shape)
         z_hat = z_hat.contiguous(memory_format=torch.channels_last)
         psi = m.hyper_decoder(z_hat)
-        wg, bg = self._ctx_weight()
+        layers = self._prepack()
         p = self.pad
-        ypad = torch.zeros((B, M, h + 2 * p, w + 2 * p), device=dev, dtype=torch.float32)
+        S1 = 2 * self.y_W + 2
+        # decoded latents, pixel-major (a pixel's M values are contiguous: one copy per step), zero frame
+        ypad = torch.zeros((B, h + 2 * p, w + 2 * p, M), device=dev, dtype=torch.float32)
+        psi_h = psi.permute(0, 2, 3, 1).contiguous()                              # [B, h, w, 2M]
+        pin = dev.type == "cuda"
+        tabs_host = torch.empty((B, M, S1), dtype=torch.int32, pin_memory=pin)
+        c_host = torch.empty((B, M), dtype=torch.int32, pin_memory=pin)
+        vals_host = torch.empty((B, M), dtype=torch.float32, pin_memory=pin)
+        tabs_np, c_np, vals_np = tabs_host.numpy().view(np.uint32), c_host.numpy(), vals_host.numpy()
+        # The per-pixel device work (4 GEMM launches, their split-K finishes, activation, table kernel) is
+        # launch-bound: capture it once as a HIP graph over static operand buffers and replay it h*w times
+        # (same kernels, same arguments: the tables stay bit-identical to the encoder's).
+        win_s = torch.zeros((B, len(self.taps) * M, 1, 1), device=dev, dtype=torch.float32)
+        psi_s = torch.zeros((B, psi_h.shape[-1], 1, 1), device=dev, dtype=torch.float32)
+        center, tables = self._params_at(win_s, psi_s, layers)                     # warm-up, and the eager fallback
+        graph = None
+        if pin and os.environ.get("LIC_CODEC_GRAPH", "1") != "0":
+            try:
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    center, tables = self._params_at(win_s, psi_s, layers)
+            except Exception:                                                      # capture unsupported: stay eager
+                graph = None
+        win_flat, psi_flat = win_s.view(B, -1), psi_s.view(B, -1)
         decs = [_StreamDecoder(s) for s in strings["y"]]
         try:
             for i in range(h):
                 for j in range(w):
-                    cols = [ypad[:, :, i + r, j + s] for (r, s) in self.taps]        # each [B, M]
-                    win = torch.cat(cols, dim=1).reshape(B, -1, 1, 1).contiguous()
-                    psi_px = psi[:, :, i, j].reshape(B, -1, 1, 1).contiguous()
-                    center, tables = self._params_at(win, psi_px, wg, bg)
-                    tabs = tables.cpu().numpy().view(np.uint32).reshape(B, M, -1)
-                    c = center.cpu().numpy()
-                    vals = np.stack([decs[b].next(tabs[b], M) + c[b] - self.y_W for b in range(B)])
-                    ypad[:, :, i + p, j + p] = torch.from_numpy(vals.astype(np.float32)).to(dev)
+                    torch.cat([ypad[:, i + r, j + s, :] for (r, s) in self.taps], dim=1, out=win_flat)
+                    psi_flat.copy_(psi_h[:, i, j, :])
+                    if graph is not None:
+                        graph.replay()
+                    else:
+                        center, tables = self._params_at(win_s, psi_s, layers)
+                    tabs_host.copy_(tables.view(B, M, S1), non_blocking=True)
+                    c_host.copy_(center.view(B, M), non_blocking=True)
+                    torch.cuda.current_stream().synchronize()
+                    for b in range(B):
+                        vals_np[b] = decs[b].next(tabs_np[b], M) + c_np[b] - self.y_W
+                    ypad[:, i + p, j + p, :].copy_(vals_host, non_blocking=True)
         finally:
             for d in decs:
                 d.close()
-        y_hat = ypad[:, :, p:p + h, p:p + w].contiguous(memory_format=torch.channels_last)
+        y_hat = ypad[:, p:p + h, p:p + w, :].permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
         x_hat = m.decoder(y_hat)
         return {"x_hat": x_hat, "y_hat": y_hat, "z_hat": z_hat}

@@ -689,8 +689,65 @@ LIC_EXPORT int lic_factorized_cdf_tables(const float* fe_params, int32_t C, int3
                      (hipStream_t)stream, fe_params, lo, S, out);
   return lic_check_launch();
 }
-// one thread per latent element: centre = rint(sum_k w_k mu_k), window [centre - W, centre + W],
+// centre = rint(sum_k w_k mu_k), window [centre - W, centre + W],
 // F(x) = sum_k w_k Phi((x - mu_k) / sigma_k)  (EntropyModels.py:192-233, utils.py:6-8)
+struct GmmElem {
+  float wk[LIC_MAXK], mu[LIC_MAXK], sg[LIC_MAXK];
+  int c;
+};
+__device__ __forceinline__ GmmElem gmm_elem(const float* params, long e, int M, int K, long CH, long T) {
+  const long pix = e / M;
+  const int m = (int)(e - pix * M);
+  const float* q = params + pix * CH;
+  GmmElem g;
+  float mean = 0.0f;
+  for (int k = 0; k < K; ++k) {
+    g.wk[k] = (K == 1) ? 1.0f : q[k * M + m];
+    g.mu[k] = (K == 1) ? q[m] : q[T + k * M + m];
+    g.sg[k] = (K == 1) ? q[M + m] : q[2 * T + k * M + m];
+    mean = __builtin_fmaf(g.wk[k], g.mu[k], mean);
+  }
+  g.c = (int)rintf(mean);
+  return g;
+}
+// quantised CDF value of window entry i (the one expression both kernels below evaluate: encoder and decoder
+// may take different kernels and must still build the same table)
+__device__ __forceinline__ unsigned gmm_entry(const GmmElem& g, int K, int W, int S, int i) {
+  const float x = (float)(g.c - W + i) - 0.5f;
+  float F = 0.0f;
+  for (int k = 0; k < K; ++k) F = __builtin_fmaf(g.wk[k], gauss_cdf((x - g.mu[k]) / g.sg[k]), F);
+  return cdf_quant(F, S);
+}
+// few elements (the serial decoder: one latent pixel at a time): one WAVE per element, the window entries
+// across the lanes, the running maximum as a wave prefix scan -- the thread-per-element loop over 2W+1 entries
+// of K error functions each took 49 us for one pixel's 192 elements
+__global__ __launch_bounds__(256) void gmm_cdf_tables_wave_kernel(const float* params, long n, int M, int K, int W,
+                                                                  int* center, unsigned* out, long CH, long T) {
+  const int lane = threadIdx.x & 63;
+  const long e = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (e >= n) return;
+  const int S = 2 * W + 1;
+  const GmmElem g = gmm_elem(params, e, M, K, CH, T);
+  unsigned* row = out + e * (long)(S + 1);
+  if (lane == 0) {
+    center[e] = g.c;
+    row[0] = 0;
+    row[S] = 65536u;
+  }
+  unsigned carry = 0;
+  for (int i0 = 1; i0 < S; i0 += 64) {
+    const int i = i0 + lane;
+    unsigned v = i < S ? gmm_entry(g, K, W, S, i) : 0u;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {  // inclusive prefix maximum over the lanes
+      const unsigned t = (unsigned)__shfl_up((int)v, o, 64);
+      if (lane >= o) v = t > v ? t : v;
+    }
+    v = v > carry ? v : carry;
+    if (i < S) row[i] = v + (unsigned)i;
+    carry = (unsigned)__shfl((int)v, 63, 64);
+  }
+}
 LIC_EXPORT int lic_gmm_cdf_tables(const float* params, int64_t P, int32_t M, int32_t K, int32_t W,
                                   int32_t* center, uint32_t* out, lic_stream_t stream) {
   if (!params || !center || !out || P <= 0 || M <= 0 || K < 1 || K > LIC_MAXK || W < 1 || W > 2047)
@@ -698,28 +755,19 @@ LIC_EXPORT int lic_gmm_cdf_tables(const float* params, int64_t P, int32_t M, int
   const long CH = (long)(K == 1 ? 2 : 3) * K * M;
   const long T = (long)K * M;
   const int S = 2 * W + 1;
+  if (P * M <= 32768 && getenv("LIC_TABLES_NO_WAVE") == nullptr) {
+    hipLaunchKernelGGL(gmm_cdf_tables_wave_kernel, dim3((unsigned)cdiv64(P * M, 4)), dim3(256), 0, (hipStream_t)stream,
+                       params, (long)(P * M), M, K, W, center, out, CH, T);
+    return lic_check_launch();
+  }
   return ew_launch(P * M, stream, [=] __device__(long e) {
-    const long pix = e / M;
-    const int m = (int)(e - pix * M);
-    const float* q = params + pix * CH;
-    float wk[LIC_MAXK], mu[LIC_MAXK], sg[LIC_MAXK];
-    float mean = 0.0f;
-    for (int k = 0; k < K; ++k) {
-      wk[k] = (K == 1) ? 1.0f : q[k * M + m];
-      mu[k] = (K == 1) ? q[m] : q[T + k * M + m];
-      sg[k] = (K == 1) ? q[M + m] : q[2 * T + k * M + m];
-      mean += wk[k] * mu[k];
-    }
-    const int c = (int)rintf(mean);
-    center[e] = c;
+    const GmmElem g = gmm_elem(params, e, M, K, CH, T);
+    center[e] = g.c;
     unsigned* row = out + e * (long)(S + 1);
     unsigned run = 0;
     row[0] = 0;
     for (int i = 1; i < S; ++i) {
-      const float x = (float)(c - W + i) - 0.5f;
-      float F = 0.0f;
-      for (int k = 0; k < K; ++k) F += wk[k] * gauss_cdf((x - mu[k]) / sg[k]);
-      const unsigned v = cdf_quant(F, S);
+      const unsigned v = gmm_entry(g, K, W, S, i);
       run = v > run ? v : run;
       row[i] = run + (unsigned)i;
     }

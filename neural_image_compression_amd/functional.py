@@ -285,6 +285,28 @@ def conv2d(x, weight, bias, stride=1, padding=0, leaky=False, slope=0.01, tap_ma
     return _ConvFn.apply(x, weight, bias, stride, padding, 0, False, leaky, slope, tap_mask, residual)
 
 
+def pack_conv_weight(weight: torch.Tensor) -> torch.Tensor:
+    """The forward B-operand layout of an nn.Conv2d weight, for `conv2d_prepacked`."""
+    _require_cuda(weight)
+    return _pack_conv_weight(weight.detach(), False, for_dgrad=False)
+
+
+@torch.no_grad()
+def conv2d_prepacked(x, w_packed, bias, cout, kernel, stride=1, padding=0, leaky=False, slope=0.01, tap_mask=0):
+    """Inference-only conv2d whose weight was packed once with `pack_conv_weight` (no autograd, no per-call
+    packing): same kernel, same operands, hence the same bits as `conv2d`.  The serial context decoder calls
+    four layers h*w times with unchanged weights (codec.ContextCodec)."""
+    _require_cuda(x, w_packed, bias)
+    xh = _nhwc(x)
+    B, Hi, Wi, Cin = xh.shape
+    Ho, Wo = conv_out_size(Hi, Wi, kernel, stride, padding, False)
+    out = torch.empty((B, Ho, Wo, cout), device=x.device, dtype=torch.float32)
+    _igemm(xh, w_packed, out, B=B, Hi=Hi, Wi=Wi, Cin=Cin, Ho=Ho, Wo=Wo, Cout=cout, kh=kernel, kw=kernel,
+           stride=stride, pad=padding, transposed=False, bias=bias,
+           epilogue=L.EPI_LEAKY if leaky else L.EPI_NONE, slope=slope, tap_mask=tap_mask)
+    return _nchw_view(out)
+
+
 def conv_transpose2d(x, weight, bias, stride=1, padding=0, output_padding=0, leaky=False, slope=0.01,
                      residual=None):
     return _ConvFn.apply(x, weight, bias, stride, padding, output_padding, True, leaky, slope, 0, residual)
