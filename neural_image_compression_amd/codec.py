@@ -8,10 +8,10 @@ EntropyModels.py:153-184; `lic_gmm_cdf_tables` from the Gaussian / mixture param
 EntropyModels.py:192-233) and the serial range coder runs on the host CPU
 (`liblic_codec.so`, include/lic_codec.h), as the north star prescribes.
 
-Scope of this round: `compress` (y and z streams), `decompress_z` (the hyper-latent has a
-parameter-free prior, so it decodes without context) and `decode_y_with_tables` (decodes y from the
-tables the encoder used -- the coder's inverse).  The raster-order loop that rebuilds those tables
-from already-decoded pixels through the masked 5x5 context model is the serial step that remains.
+`LatentCodec`: `compress` (y and z streams), `decompress_z` (the hyper-latent has a parameter-free
+prior, so it decodes without context) and `decode_y_with_tables` (decodes y from the tables the encoder
+used -- the coder's inverse).  `ContextCodec`: the full round trip; its decoder rebuilds the tables from
+already-decoded pixels through the masked 5x5 context model, wavefront by wavefront.
 """
 from __future__ import annotations
 
@@ -212,15 +212,17 @@ class _StreamDecoder:
 class ContextCodec:
     """compress(x) -> byte strings, decompress(strings) -> x_hat, through the model's masked-conv
     context (ContextModels.py:3-36): the parameters of pixel (i, j) of y depend on the already decoded
-    pixels above / left of it, so decoding walks the latent grid in raster order -- h*w dependent
-    steps of {12-tap context GEMM -> entropy-parameter MLP -> table kernel} on the GPU and M symbols
-    per image on the host coder.
+    pixels above / left of it, so decoding is serial -- but only along a wavefront: pixels with equal
+    j + 3 i are independent (see _wavefront), so it takes w + 3 (h - 1) dependent steps of {12-tap context
+    GEMM -> entropy-parameter MLP -> table kernel} on the GPU, each over a batch of pixels, and their
+    symbols on the host coder in between.
 
     Encoder and decoder must build BIT-IDENTICAL tables, so both evaluate the context as the same
     per-pixel GEMM over the 12 live taps ([N, 12M, 1, 1] "images": the kernels' results for one row do
     not depend on the batch it sits in, and their split-K choice depends on per-image geometry only --
     the property tests/test_gpu_fullsize.py pins); the encoder simply has all N = B*h*w pixels at
-    once.  One y stream per image (symbol order i, j, m) + one z stream for the batch."""
+    once.  One y stream per image (symbols step by step, pixel by pixel, channel by channel) + one z stream
+    for the batch."""
 
     def __init__(self, model, z_lo: int = -64, z_S: int = 129, y_W: int = 32):
         self.model, self.z_lo, self.z_S, self.y_W = model, int(z_lo), int(z_S), int(y_W)
@@ -228,6 +230,23 @@ class ContextCodec:
         k = mc.kernel_size[0]
         self.taps = [(r, s) for r in range(k) for s in range(k) if (mc._tap_mask >> (r * k + s)) & 1]
         self.k, self.pad = k, mc.padding[0]
+        # the wavefront schedule (_wavefront) needs every live tap strictly earlier: ds + (pad + 1) * dr < 0
+        if any((s - self.pad) + (self.pad + 1) * (r - self.pad) >= 0 for (r, s) in self.taps):
+            raise CodecError("context mask is not causal in raster order")
+
+    def _wavefront(self, h: int, w: int):
+        """Decode schedule.  With mask type A a pixel (i, j) sees rows above it up to column j + pad and its own
+        row up to j - 1, so for t = j + (pad + 1) * i every pixel's context lies in steps < t: the pixels of one
+        step are independent and go through the GPU as one batch -- w + (pad + 1)(h - 1) dependent steps
+        instead of h * w (141 instead of 1536 for a 512x768 image).  Returns [(rows, cols)] per step, rows
+        ascending; encoder and decoder order the symbols step by step, pixel by pixel, channel by channel."""
+        k = self.pad + 1
+        steps = []
+        for t in range(w + k * (h - 1)):
+            ii = np.array([i for i in range(h) if 0 <= t - k * i < w], dtype=np.int64)
+            if ii.size:
+                steps.append((ii, t - k * ii))
+        return steps
 
     def _ctx_weight(self):
         mc = self.model.context_model.masked
@@ -283,8 +302,10 @@ class ContextCodec:
         psi_px = psi.permute(0, 2, 3, 1).reshape(B * h * w, -1, 1, 1).contiguous()
         center, tables = self._params_at(self._windows_all(y_in), psi_px, self._prepack())
         y_sym = y_in.permute(0, 2, 3, 1).reshape(B * h * w, M).round().to(torch.int32)
-        idx = (y_sym - center + self.y_W).cpu().numpy().reshape(B, h * w * M)
-        tabs = tables.cpu().numpy().view(np.uint32).reshape(B, h * w * M, -1)
+        # symbols leave in the decoder's wavefront order (see _wavefront), M channels per pixel
+        perm = torch.from_numpy(np.concatenate([ii * w + jj for ii, jj in self._wavefront(h, w)])).to(y_in.device)
+        idx = (y_sym - center + self.y_W).view(B, h * w, M)[:, perm].cpu().numpy().reshape(B, h * w * M)
+        tabs = tables.view(B, h * w, M, -1)[:, perm].cpu().numpy().view(np.uint32).reshape(B, h * w * M, -1)
         y_streams = [rc_encode(tabs[b], idx[b]) for b in range(B)]
         npix = x.shape[0] * x.shape[2] * x.shape[3]
         coded = 8.0 * (len(z_bytes) + sum(len(s) for s in y_streams)) / npix
@@ -303,46 +324,30 @@ class ContextCodec:
         layers = self._prepack()
         p = self.pad
         S1 = 2 * self.y_W + 2
-        # decoded latents, pixel-major (a pixel's M values are contiguous: one copy per step), zero frame
+        # decoded latents, pixel-major, inside a zero frame
         ypad = torch.zeros((B, h + 2 * p, w + 2 * p, M), device=dev, dtype=torch.float32)
         psi_h = psi.permute(0, 2, 3, 1).contiguous()                              # [B, h, w, 2M]
+        steps = self._wavefront(h, w)
+        nmax = max(len(ii) for ii, _ in steps)
         pin = dev.type == "cuda"
-        tabs_host = torch.empty((B, M, S1), dtype=torch.int32, pin_memory=pin)
-        c_host = torch.empty((B, M), dtype=torch.int32, pin_memory=pin)
-        vals_host = torch.empty((B, M), dtype=torch.float32, pin_memory=pin)
+        tabs_host = torch.empty((B, nmax * M, S1), dtype=torch.int32, pin_memory=pin)
+        c_host = torch.empty((B, nmax * M), dtype=torch.int32, pin_memory=pin)
+        vals_host = torch.empty((B, nmax * M), dtype=torch.float32, pin_memory=pin)
         tabs_np, c_np, vals_np = tabs_host.numpy().view(np.uint32), c_host.numpy(), vals_host.numpy()
-        # The per-pixel device work (4 GEMM launches, their split-K finishes, activation, table kernel) is
-        # launch-bound: capture it once as a HIP graph over static operand buffers and replay it h*w times
-        # (same kernels, same arguments: the tables stay bit-identical to the encoder's).
-        win_s = torch.zeros((B, len(self.taps) * M, 1, 1), device=dev, dtype=torch.float32)
-        psi_s = torch.zeros((B, psi_h.shape[-1], 1, 1), device=dev, dtype=torch.float32)
-        center, tables = self._params_at(win_s, psi_s, layers)                     # warm-up, and the eager fallback
-        graph = None
-        if pin and os.environ.get("LIC_CODEC_GRAPH", "1") != "0":
-            try:
-                torch.cuda.synchronize()
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    center, tables = self._params_at(win_s, psi_s, layers)
-            except Exception:                                                      # capture unsupported: stay eager
-                graph = None
-        win_flat, psi_flat = win_s.view(B, -1), psi_s.view(B, -1)
         decs = [_StreamDecoder(s) for s in strings["y"]]
         try:
-            for i in range(h):
-                for j in range(w):
-                    torch.cat([ypad[:, i + r, j + s, :] for (r, s) in self.taps], dim=1, out=win_flat)
-                    psi_flat.copy_(psi_h[:, i, j, :])
-                    if graph is not None:
-                        graph.replay()
-                    else:
-                        center, tables = self._params_at(win_s, psi_s, layers)
-                    tabs_host.copy_(tables.view(B, M, S1), non_blocking=True)
-                    c_host.copy_(center.view(B, M), non_blocking=True)
-                    torch.cuda.current_stream().synchronize()
-                    for b in range(B):
-                        vals_np[b] = decs[b].next(tabs_np[b], M) + c_np[b] - self.y_W
-                    ypad[:, i + p, j + p, :].copy_(vals_host, non_blocking=True)
+            for ii, jj in steps:
+                n = len(ii)
+                it, jt = torch.from_numpy(ii).to(dev), torch.from_numpy(jj).to(dev)
+                win = torch.cat([ypad[:, it + r, jt + s, :] for (r, s) in self.taps], dim=2)   # [B, n, 12M]
+                center, tables = self._params_at(win.reshape(B * n, -1, 1, 1),
+                                                 psi_h[:, it, jt, :].reshape(B * n, -1, 1, 1), layers)
+                tabs_host[:, :n * M].copy_(tables.view(B, n * M, S1), non_blocking=True)
+                c_host[:, :n * M].copy_(center.view(B, n * M), non_blocking=True)
+                torch.cuda.current_stream().synchronize()
+                for b in range(B):
+                    vals_np[b, :n * M] = decs[b].next(tabs_np[b, :n * M], n * M) + c_np[b, :n * M] - self.y_W
+                ypad[:, it + p, jt + p, :] = vals_host[:, :n * M].to(dev, non_blocking=True).view(B, n, M)
         finally:
             for d in decs:
                 d.close()

@@ -159,7 +159,7 @@ def test_coded_bpp_matches_estimate_and_round_trips(codec, K):
 @pytest.mark.gpu
 @pytest.mark.parametrize("K,B,H,W", [(1, 2, 64, 128), (3, 1, 128, 64)])
 def test_context_codec_full_round_trip(codec, K, B, H, W):
-    """compress -> bytes -> decompress through the raster-order masked-conv context: the decoded
+    """compress -> bytes -> decompress through the masked-conv context (wavefront schedule): the decoded
     latents equal the encoder's exactly, x_hat equals the model's eval output, coded ~ estimated."""
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
