@@ -205,3 +205,27 @@ def test_evaluator_reports_coded_bpp(codec, tmp_path):
     assert abs(m["BPP(coded)"] - m["BPP(total)"]) <= 0.02 * m["BPP(total)"] + 128.0 / (192 * 256)
     m2, _, _ = ev.evaluate(nic.rd_loss)
     assert "BPP(coded)" not in m2 and m2["BPP(total)"] == m["BPP(total)"]
+
+
+@pytest.mark.parametrize("h,w", [(1, 1), (4, 4), (4, 8), (32, 48), (7, 3)])
+def test_wavefront_schedule_is_causal_and_complete(codec, h, w):
+    """every latent pixel appears exactly once, and each live tap of the type-A 5x5 mask belongs to an
+    earlier step (or lies outside the image)"""
+    cc = object.__new__(codec.ContextCodec)
+    cc.pad = 2
+    steps = cc._wavefront(h, w)
+    assert len(steps) <= w + 3 * (h - 1)
+    step_of = -np.ones((h, w), np.int64)
+    for t, (ii, jj) in enumerate(steps):
+        assert (np.diff(ii) > 0).all()
+        assert (step_of[ii, jj] == -1).all()
+        step_of[ii, jj] = t
+    assert (step_of >= 0).all()
+    taps = [(r, s) for r in range(5) for s in range(5) if r < 2 or (r == 2 and s < 2)]   # 12 live taps
+    assert len(taps) == 12
+    for i in range(h):
+        for j in range(w):
+            for r, s in taps:
+                a, b = i + r - 2, j + s - 2
+                if 0 <= a < h and 0 <= b < w:
+                    assert step_of[a, b] < step_of[i, j]
