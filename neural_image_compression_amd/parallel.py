@@ -19,7 +19,7 @@ import torch.distributed as dist
 
 class GradientAllReducer:
     def __init__(self, params, process_group=None, bucket_mb: float = 16.0, overlap: bool = True,
-                 force: bool = False, stream_groups=None, group_streams=None, tail_mb: float = 1.0):
+                 force: bool = False, stream_groups=None, group_streams=None):
         """`force`: run the hooks and collectives even on a single rank (rehearses the data path and its
         stream interplay on a one-GPU box; the result is unchanged: sum of one, mean of one)."""
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
@@ -53,17 +53,7 @@ class GradientAllReducer:
                 cur.append(i)
                 cur_n += n
             if cur:
-                # The group's last bucket closes with the gradients backward produces last (the first
-                # layers' weights), and its exchange is the one nothing is left to hide behind: peel the
-                # trailing <= `tail_mb` of it off into a bucket of its own so the large part starts earlier
-                # and only a latency-sized collective is exposed after the last kernel.
-                tail, tail_n = [], 0
-                while len(cur) > 1 and tail_n + self.params[cur[-1]].numel() <= int(tail_mb * 1024 * 1024 / 4):
-                    tail_n += self.params[cur[-1]].numel()
-                    tail.insert(0, cur.pop())
                 self.buckets.append(cur)
-                if tail:
-                    self.buckets.append(tail)
         self._bucket_of = {}
         for b, idxs in enumerate(self.buckets):
             for i in idxs:
