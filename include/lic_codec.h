@@ -38,7 +38,8 @@ int lic_rc_decode(const uint8_t* in, size_t nbytes, const uint32_t* tables, cons
                   int64_t n, int32_t* idx_out);
 
 /* Streaming decoder: the tables of later symbols may depend on symbols already decoded (the
- * raster-order context model).  `in` must stay valid until lic_rc_decoder_free. */
+ * masked-conv context model, decoded wavefront by wavefront: codec.ContextCodec).  `in` must stay valid until
+ * lic_rc_decoder_free. */
 typedef struct lic_rc_decoder lic_rc_decoder;
 lic_rc_decoder* lic_rc_decoder_new(const uint8_t* in, size_t nbytes);
 int lic_rc_decoder_next(lic_rc_decoder* dec, const uint32_t* tables, const int32_t* table_of, int32_t S, int64_t n,
