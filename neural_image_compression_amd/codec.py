@@ -329,6 +329,16 @@ class ContextCodec:
         psi_h = psi.permute(0, 2, 3, 1).contiguous()                              # [B, h, w, 2M]
         steps = self._wavefront(h, w)
         nmax = max(len(ii) for ii, _ in steps)
+        # flat indices of every step's context windows / own pixels, uploaded once: one gather per step
+        Wp = w + 2 * p
+        tr = np.array([r for (r, _) in self.taps]), np.array([c for (_, c) in self.taps])
+        win_idx = torch.from_numpy(np.concatenate(
+            [((ii[:, None] + tr[0][None, :]) * Wp + jj[:, None] + tr[1][None, :]).ravel() for ii, jj in steps])).to(dev)
+        own_idx = torch.from_numpy(np.concatenate([(ii + p) * Wp + jj + p for ii, jj in steps])).to(dev)
+        psi_idx = torch.from_numpy(np.concatenate([ii * w + jj for ii, jj in steps])).to(dev)
+        yflat = ypad.view(B, -1, M)
+        psi_flat = psi_h.view(B, h * w, -1)
+        nt = len(self.taps)
         pin = dev.type == "cuda"
         tabs_host = torch.empty((B, nmax * M, S1), dtype=torch.int32, pin_memory=pin)
         c_host = torch.empty((B, nmax * M), dtype=torch.int32, pin_memory=pin)
@@ -336,18 +346,20 @@ class ContextCodec:
         tabs_np, c_np, vals_np = tabs_host.numpy().view(np.uint32), c_host.numpy(), vals_host.numpy()
         decs = [_StreamDecoder(s) for s in strings["y"]]
         try:
-            for ii, jj in steps:
+            off = 0
+            for ii, _ in steps:
                 n = len(ii)
-                it, jt = torch.from_numpy(ii).to(dev), torch.from_numpy(jj).to(dev)
-                win = torch.cat([ypad[:, it + r, jt + s, :] for (r, s) in self.taps], dim=2)   # [B, n, 12M]
-                center, tables = self._params_at(win.reshape(B * n, -1, 1, 1),
-                                                 psi_h[:, it, jt, :].reshape(B * n, -1, 1, 1), layers)
+                win = yflat.index_select(1, win_idx[off * nt:(off + n) * nt])             # [B, n*12, M]
+                center, tables = self._params_at(win.view(B * n, nt * M, 1, 1),
+                                                 psi_flat.index_select(1, psi_idx[off:off + n]).view(B * n, -1, 1, 1),
+                                                 layers)
                 tabs_host[:, :n * M].copy_(tables.view(B, n * M, S1), non_blocking=True)
                 c_host[:, :n * M].copy_(center.view(B, n * M), non_blocking=True)
                 torch.cuda.current_stream().synchronize()
                 for b in range(B):
                     vals_np[b, :n * M] = decs[b].next(tabs_np[b, :n * M], n * M) + c_np[b, :n * M] - self.y_W
-                ypad[:, it + p, jt + p, :] = vals_host[:, :n * M].to(dev, non_blocking=True).view(B, n, M)
+                yflat.index_copy_(1, own_idx[off:off + n], vals_host[:, :n * M].to(dev, non_blocking=True).view(B, n, M))
+                off += n
         finally:
             for d in decs:
                 d.close()
