@@ -7,6 +7,7 @@
 #include "lic_common.h"
 #include <stdio.h>
 #include <stdlib.h>
+#include <type_traits>
 
 thread_local int g_lic_last_hip_error = 0;
 
@@ -97,8 +98,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   constexpr int APASS = BM / 64;           // float4 A loads per thread per chunk
   // A double buffer; after the K loop the same memory stages 32x32 output tiles (one per wave)
   constexpr int GL_BUF = (BM + BN) * IG_BK;  // GLDS: floats of one (A tile, B panel) buffer
-  constexpr int SA_MAIN = GLDS ? 2 * GL_BUF : ((2 * BM * IG_LDA > 4 * 1024) ? 2 * BM * IG_LDA : 4 * 1024);
-  static_assert(!GLDS || (VEC && FULLN && 2 * GL_BUF >= 4 * 1024), "LDS-DMA variant: float4 gathers, full N");
+  constexpr int GL_NBUF = 3;  // ring of three (A tile, B panel) buffers, see the loop
+  constexpr int SA_MAIN = GLDS ? GL_NBUF * GL_BUF : ((2 * BM * IG_LDA > 4 * 1024) ? 2 * BM * IG_LDA : 4 * 1024);
+  static_assert(!GLDS || (VEC && FULLN && GL_NBUF * GL_BUF >= 4 * 1024), "LDS-DMA variant: float4 gathers, full N");
   // fused GDN epilogue: x tile [64][BN+4] + one 32x32 patch per wave
   constexpr int SA_FLOATS = (FUSE && 64 * (BN + 4) + 4096 > SA_MAIN) ? 64 * (BN + 4) + 4096 : SA_MAIN;
   static_assert(!FUSE || (VEC && FULLN), "fused GDN epilogue: float4 gathers, full N");
@@ -387,52 +389,99 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
         __builtin_amdgcn_global_load_lds((lic_gptr_t)(wsrc + j * 1024), (lic_lptr_t)(dstB + j * 1024 + wave * 256),
                                          16, 0, 0);
     };
-    auto compute_g = [&](int buf) {
-      const float* bA = smem + buf * GL_BUF;
-      const float* bB = bA + BM * IG_BK + (wn0 >> 5) * 512 + lane * 4;
-      f32x4 af[TM][2], bf[TN][2];
+    // Fragments of half a chunk (k-steps 4h .. 4h+3): TM + TN ds_read_b128 per lane.  The reads are inline
+    // asm: left to hipcc, every fragment read is followed by `s_waitcnt lgkmcnt(0)` in front of the next MFMA
+    // group whether that group uses it or not, which puts the LDS latency back in front of the matrix pipe.
+    // With asm the waits are ours to place (LDS returns in order: lgkmcnt(TM + TN) leaves exactly the
+    // youngest half-chunk's reads in flight).
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)&smem[0];
+    unsigned fa_addr[TM][2];
 #pragma unroll
-      for (int a = 0; a < TM; ++a) {
-        const int row = wm0 + a * 32 + li;
-        const int sw = (row >> 2) & 3;
-        af[a][0] = *reinterpret_cast<const f32x4*>(bA + row * IG_BK + (((lh * 2) ^ sw) * 4));
-        af[a][1] = *reinterpret_cast<const f32x4*>(bA + row * IG_BK + (((lh * 2 + 1) ^ sw) * 4));
-      }
+    for (int a = 0; a < TM; ++a) {
+      const int row = wm0 + a * 32 + li;
+      const int sw = (row >> 2) & 3;
 #pragma unroll
-      for (int b = 0; b < TN; ++b) {
-        bf[b][0] = *reinterpret_cast<const f32x4*>(bB + b * 512);
-        bf[b][1] = *reinterpret_cast<const f32x4*>(bB + b * 512 + 256);
-      }
+      for (int h = 0; h < 2; ++h) fa_addr[a][h] = lds0 + 4u * (unsigned)(row * IG_BK + (((lh * 2 + h) ^ sw) * 4));
+    }
+    const unsigned fb_addr = lds0 + 4u * (unsigned)(BM * IG_BK + (wn0 >> 5) * 512 + lane * 4);
+    auto read_h = [&](auto bufc, auto hc, f32x4 (&af)[TM], f32x4 (&bf)[TN]) {
+      constexpr int buf = decltype(bufc)::value, h = decltype(hc)::value;
 #pragma unroll
-      for (int t = 0; t < 8; ++t)
+      for (int a = 0; a < TM; ++a)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[a]) : "v"(fa_addr[a][h]), "i"(buf * GL_BUF * 4));
+      if constexpr (TN >= 1)
+        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bf[0]) : "v"(fb_addr), "i"(buf * GL_BUF * 4 + h * 1024));
+      if constexpr (TN >= 2)
+        asm volatile("ds_read_b128 %0, %1 offset:%2"
+                     : "=v"(bf[TN >= 2 ? 1 : 0])
+                     : "v"(fb_addr), "i"(buf * GL_BUF * 4 + 2048 + h * 1024));
+      if constexpr (TN >= 3)
+        asm volatile("ds_read_b128 %0, %1 offset:%2"
+                     : "=v"(bf[TN >= 3 ? 2 : 0])
+                     : "v"(fb_addr), "i"(buf * GL_BUF * 4 + 4096 + h * 1024));
+    };
+    // wait until at most `newer` LDS reads are in flight; the fragments pass through, so that the MFMAs that
+    // use them cannot be scheduled above the wait
+    auto arrive = [&](auto newerc, f32x4 (&af)[TM], f32x4 (&bf)[TN]) {
+      asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(decltype(newerc)::value) : "memory");
+#pragma unroll
+      for (int a = 0; a < TM; ++a) asm volatile("" : "+v"(af[a]));
+#pragma unroll
+      for (int b = 0; b < TN; ++b) asm volatile("" : "+v"(bf[b]));
+    };
+    auto mfma_h = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN]) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int b = 0; b < TN; ++b)
 #pragma unroll
           for (int a = 0; a < TM; ++a)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][t >> 2][t & 3], bf[b][t >> 2][t & 3],
-                                                              acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][t], bf[b][t], acc[a][b], 0, 0, 0);
     };
     if (nchunks > 0) {
-      // Two buffers; per chunk: __syncthreads (vmcnt(0): my DMA of chunk c landed; barrier: everyone's
-      // did and everyone is done reading chunk c-1) -> issue the DMA of chunk c+1 -> MFMAs of chunk c.
+      // Ring of three buffers, fragments one half-chunk ahead of the MFMAs that use them.  At the top of step c
+      // chunk c+1 (DMA issued a whole step earlier) has landed everywhere and everyone is done reading chunk
+      // c-1, whose buffer takes chunk c+2.  The wave already holds the first-half fragments of chunk c; it
+      // reads the second half, runs the first half's 4*TM*TN MFMAs, re-uses those registers for the first-half
+      // fragments of chunk c+1, and runs the second half: no MFMA waits for the ds_read in front of it.
+      // (Unrolled by three: buffer numbers are compile-time constants.  Past-the-end chunks are clamped
+      // duplicates, so the prefetch past the last chunk reads valid data that is never used.)
+      using I0 = std::integral_constant<int, 0>;
+      using I1 = std::integral_constant<int, 1>;
+      using I2 = std::integral_constant<int, 2>;
+      using NF = std::integral_constant<int, TM + TN>;
+      f32x4 a0[TM], b0[TN], a1[TM], b1[TN];
       issue(l_tap, l_cb, 0);
       advance();
-      int c = 0;
-      for (; c + 1 < nchunks; c += 2) {  // branch-free body, single exit; past-the-end DMAs are duplicates
-        __syncthreads();
-        issue(l_tap, l_cb, 1);
-        advance();
-        compute_g(0);
-        __builtin_amdgcn_sched_barrier(0);  // keep the vmcnt(0)+barrier BEHIND this chunk's MFMAs
-        __syncthreads();
-        issue(l_tap, l_cb, 0);
-        advance();
-        compute_g(1);
+      issue(l_tap, l_cb, 1);
+      advance();
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(APASS + TN) : "memory");  // chunk 0 is in
+      read_h(I0{}, I0{}, a0, b0);
+      auto step = [&](auto cur, auto nxt, auto fill) {
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        read_h(cur, I1{}, a1, b1);
+        arrive(NF{}, a0, b0);  // the first half is in (read a half-step ago); the second half stays in flight
         __builtin_amdgcn_sched_barrier(0);
+        issue(l_tap, l_cb, decltype(fill)::value);  // its address arithmetic threads between the MFMAs below
+        advance();
+        mfma_h(a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
+        read_h(nxt, I0{}, a0, b0);
+        arrive(NF{}, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_h(a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      int c = 0;
+      for (; c + 2 < nchunks; c += 3) {
+        step(I0{}, I1{}, I2{});
+        step(I1{}, I2{}, I0{});
+        step(I2{}, I0{}, I1{});
       }
-      __syncthreads();
-      if (c < nchunks) compute_g(0);
-      __syncthreads();  // the epilogue reuses the buffers
+      if (c < nchunks) step(I0{}, I1{}, I2{});
+      if (c + 1 < nchunks) step(I1{}, I2{}, I0{});
+      arrive(I0{}, a0, b0);  // the last prefetch must land before its registers are reused
+      __syncthreads();       // drains the duplicate tail DMAs; the epilogue reuses the buffers
     }
   } else {
   f32x4 rb0[TN][2], rb1[TN][2];
