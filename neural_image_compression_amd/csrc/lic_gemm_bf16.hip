@@ -75,12 +75,8 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
   constexpr int BUF = (BM + BN) * HB_BK;      // bf16 elements of one (A tile, B panel) buffer
   // three DMA buffers, later reused as the fp32 staging area of the epilogue (4 KiB per wave);
   // a plain 2-D array indexed with compile-time buffer numbers, so hipcc can tell the buffers apart
-  // PIPE (TN <= 2: four buffers are 64 KiB, two workgroups per CU still fit): fragments are read half a chunk
-  // ahead of their MFMAs, see the loop; the 128x192 tile keeps the three-buffer loop (80 KiB would halve occupancy)
-  constexpr bool PIPE = TN <= 2;
-  constexpr int NB = PIPE ? 4 : 3;
-  constexpr int BUFP = (NB * BUF * 2 >= 4 * 4096) ? BUF : (4 * 4096 / 2 + NB - 1) / NB;
-  __shared__ __attribute__((aligned(16))) bf16_t smem_all[NB * BUFP + 64];  // + the decoded tap list
+  constexpr int BUFP = (3 * BUF * 2 >= 4 * 4096) ? BUF : (4 * 4096 / 2 + 2) / 3;
+  __shared__ __attribute__((aligned(16))) bf16_t smem_all[3 * BUFP + 64];  // + the decoded tap list
   auto bufp = [&](int b) { return smem_all + b * BUFP; };
 
   const int tid = threadIdx.x;
@@ -157,7 +153,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
   // global load whose wait drains the whole in-order DMA queue
   // (kept INSIDE the one staging array: a second __shared__ object next to LDS-DMA buffers makes
   // hipcc wait vmcnt(0) before every LDS read)
-  int* s_taps = reinterpret_cast<int*>(smem_all + NB * BUFP);
+  int* s_taps = reinterpret_cast<int*>(smem_all + 3 * BUFP);
   if (tid < 28) {
     const int tt = p.taps[phase][tid < ntaps ? tid : 0];
     const int tr = tt / p.kw;
@@ -243,98 +239,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
       ++l_tap;
     }
   };
-  if constexpr (PIPE) {
-    // Ring of FOUR buffers: at the top of step c the DMAs of chunks c+1 and c+2 are in flight; vmcnt(NL) retires
-    // mine of chunk c+1, the barrier says everyone's landed and everyone finished reading chunk c-1, whose
-    // buffer takes chunk c+3.  So chunk c+1 is readable during step c, and the fragments run half a chunk ahead
-    // of the MFMAs that use them, across the barrier too: with only 2*TM*TN MFMAs of 32 cycles per chunk the
-    // `lgkmcnt(0)` hipcc puts between the fragment reads and the MFMAs was an LDS round trip per 256 matrix cycles.
-    // Reads are inline asm, waits placed by hand (LDS returns in order: lgkmcnt(TM+TN) leaves the youngest half).
-    if (nchunks > 0) {
-      const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) void*)&smem_all[0];
-      unsigned fa_addr[TM][2];
-#pragma unroll
-      for (int a = 0; a < TM; ++a) {
-        const int row = wm0 + a * 32 + li;
-        const int sw = (row >> 2) & 3;
-#pragma unroll
-        for (int q = 0; q < 2; ++q) fa_addr[a][q] = lds0 + 2u * (unsigned)(row * HB_BK + (((q * 2 + lh) ^ sw) * 8));
-      }
-      const unsigned fb_addr = lds0 + 2u * (unsigned)(BM * HB_BK + (wn0 >> 5) * 1024 + lane * 8);
-      auto read_h = [&](auto bufc, auto qc, bf16x8 (&af)[TM], bf16x8 (&bf)[TN]) {
-        constexpr int buf = decltype(bufc)::value, q = decltype(qc)::value;
-        const unsigned fb = fb_addr;
-#pragma unroll
-        for (int a = 0; a < TM; ++a) {
-          const unsigned ad = fa_addr[a][q];
-          asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[a]) : "v"(ad), "i"(buf * BUFP * 2));
-        }
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(bf[0]) : "v"(fb), "i"(buf * BUFP * 2 + q * 1024));
-        if constexpr (TN >= 2)
-          asm volatile("ds_read_b128 %0, %1 offset:%2"
-                       : "=v"(bf[TN >= 2 ? 1 : 0]) : "v"(fb), "i"(buf * BUFP * 2 + 2048 + q * 1024));
-      };
-      auto arrive = [&](auto newerc, bf16x8 (&af)[TM], bf16x8 (&bf)[TN]) {
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"i"(decltype(newerc)::value) : "memory");
-#pragma unroll
-        for (int a = 0; a < TM; ++a) {
-          asm volatile("" : "+v"(af[a]));
-          if constexpr (SQ) af[a] = sq8(af[a]);
-        }
-#pragma unroll
-        for (int b = 0; b < TN; ++b) asm volatile("" : "+v"(bf[b]));
-      };
-      auto mfma_h = [&](const bf16x8 (&af)[TM], const bf16x8 (&bf)[TN]) {
-#pragma unroll
-        for (int b = 0; b < TN; ++b)
-#pragma unroll
-          for (int a = 0; a < TM; ++a)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bf[b], acc[a][b], 0, 0, 0);
-      };
-      using I0 = std::integral_constant<int, 0>;
-      using I1 = std::integral_constant<int, 1>;
-      using I2 = std::integral_constant<int, 2>;
-      using I3 = std::integral_constant<int, 3>;
-      using NF = std::integral_constant<int, TM + TN>;
-      bf16x8 a0[TM], b0[TN], a1[TM], b1[TN];
-      issue(l_tap, l_cb, I0{});
-      advance();
-      issue(l_tap, l_cb, I1{});
-      advance();
-      issue(l_tap, l_cb, I2{});
-      advance();
-      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(2 * NL) : "memory");  // chunk 0 is in
-      read_h(I0{}, I0{}, a0, b0);
-      auto step = [&](auto cur, auto nxt, auto fill) {
-        asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(NL) : "memory");
-        read_h(cur, I1{}, a1, b1);
-        arrive(NF{}, a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        issue(l_tap, l_cb, fill);  // its address arithmetic threads between the MFMAs below
-        advance();
-        mfma_h(a0, b0);
-        __builtin_amdgcn_sched_barrier(0);
-        read_h(nxt, I0{}, a0, b0);
-        arrive(NF{}, a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_h(a1, b1);
-        __builtin_amdgcn_sched_barrier(0);
-      };
-      int c = 0;
-      for (; c + 3 < nchunks; c += 4) {
-        step(I0{}, I1{}, I3{});
-        step(I1{}, I2{}, I0{});
-        step(I2{}, I3{}, I1{});
-        step(I3{}, I0{}, I2{});
-      }
-      if (c < nchunks) step(I0{}, I1{}, I3{});
-      if (c + 1 < nchunks) step(I1{}, I2{}, I0{});
-      if (c + 2 < nchunks) step(I2{}, I3{}, I1{});
-      arrive(I0{}, a0, b0);  // the last prefetch must land before its registers are reused
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();  // the epilogue reuses the buffers
-    }
-  } else if (nchunks > 0) {
+  if (nchunks > 0) {
     // Ring of three buffers, unrolled by three so that buffer indices are compile-time constants.
     // At the top of a step the DMAs of chunks c and c+1 are in flight: vmcnt(NL) retires mine of
     // chunk c, the barrier says everyone's landed and everyone finished reading chunk c-1, whose
