@@ -28,7 +28,7 @@
 extern "C" {
 #endif
 
-#define LIC_ABI_VERSION 2
+#define LIC_ABI_VERSION 3
 
 typedef void* lic_stream_t; /* hipStream_t */
 
@@ -100,6 +100,14 @@ typedef struct lic_igemm_desc {
   size_t workspace_bytes;
   float* out3;       /* LIC_EPI_CONV_GDN / CONV_IGDN: the pre-normalisation conv output, or NULL */
   int64_t out3_ld;
+  /* Overrides of the launch plan, 0 = automatic.  The automatic tile depends on the batch (a 128-row
+   * tile needs >= 512 workgroups), so parity tests use these to put every kernel variant the full-size
+   * workloads dispatch in front of the oracle at sizes the oracle finishes in seconds, and the entropy
+   * coder pins one variant so that encoder and decoder build bit-identical tables whatever their batch.
+   *   force_bm in {64,128}, force_tn in {1,2,3} (both or neither; needs float4-aligned operands and
+   *   ceil32(Cout) % (64*force_tn) == 0, else LIC_ERR_UNSUPPORTED); force_split >= 1: K splits
+   *   (1 = never split; needs `workspace`). */
+  int32_t force_bm, force_tn, force_split, reserved0;
 } lic_igemm_desc;
 
 /* 1 when lic_igemm can run LIC_EPI_CONV_GDN / LIC_EPI_CONV_IGDN for these channel counts
@@ -147,6 +155,10 @@ typedef struct lic_wgrad_desc {
   int32_t g_is_row;
   int32_t sq_p, sq_g;
   float scale;
+  /* overrides of the launch plan, 0 = automatic (see lic_igemm_desc): tile in 64-channel units, one of
+   * (1,1) (1,3) (2,1) (2,2) (2,3) (3,3) -- (3,3) needs both channel counts % 192 == 0 -- and the number
+   * of pixel splits */
+  int32_t force_tm, force_tn, force_split;
 } lic_wgrad_desc;
 
 size_t lic_wgrad_workspace_bytes(const lic_wgrad_desc* d);
@@ -250,6 +262,10 @@ int64_t lic_packed_weight_bf16_elems(int32_t taps, int32_t K, int32_t N);
 int lic_pack_weight_bf16(const float* src, void* dst, int32_t taps, int32_t K, int32_t N, int64_t s_tap,
                          int64_t s_k, int64_t s_n, lic_stream_t stream);
 int lic_igemm_bf16(const lic_igemm_desc* d, int32_t out_f32, lic_stream_t stream);
+/* names of the kernel variants lic_igemm_bf16 / lic_wgrad_bf16 launch for `d`, as rocprofv3 prints them
+ * (force_bm of the descriptor is honoured; the N tile follows from the channel count) */
+int lic_igemm_bf16_kernel_name(const lic_igemm_desc* d, char* buf, size_t n);
+int lic_wgrad_bf16_kernel_name(const lic_wgrad_desc* d, char* buf, size_t n);
 size_t lic_wgrad_bf16_workspace_bytes(const lic_wgrad_desc* d);
 int lic_wgrad_bf16(const lic_wgrad_desc* d, void* workspace, size_t workspace_bytes, lic_stream_t stream);
 /* fp32 image -> bf16 columns; bf16 columns -> fp32 image (+ fp32 bias) */

@@ -28,7 +28,8 @@ class IgemmDesc(C.Structure):
                 ("kh", _i32), ("kw", _i32), ("stride", _i32), ("pad", _i32),
                 ("transposed", _i32), ("prologue", _i32), ("epilogue", _i32),
                 ("tap_mask", C.c_uint32), ("slope", _f32), ("workspace", _vp), ("workspace_bytes", _sz),
-                ("out3", _vp), ("out3_ld", _i64)]
+                ("out3", _vp), ("out3_ld", _i64),
+                ("force_bm", _i32), ("force_tn", _i32), ("force_split", _i32), ("reserved0", _i32)]
 
 
 class WgradDesc(C.Structure):
@@ -38,7 +39,8 @@ class WgradDesc(C.Structure):
                 ("B", _i32), ("Hs", _i32), ("Ws", _i32), ("Cp", _i32),
                 ("Hl", _i32), ("Wl", _i32), ("Cg", _i32),
                 ("kh", _i32), ("kw", _i32), ("stride", _i32), ("pad", _i32),
-                ("g_is_row", _i32), ("sq_p", _i32), ("sq_g", _i32), ("scale", _f32)]
+                ("g_is_row", _i32), ("sq_p", _i32), ("sq_g", _i32), ("scale", _f32),
+                ("force_tm", _i32), ("force_tn", _i32), ("force_split", _i32)]
 
 
 # name -> (restype, argtypes); every symbol declared in include/lic.h
@@ -78,6 +80,8 @@ SIGNATURES = {
     "lic_packed_weight_bf16_elems": (_i64, [_i32, _i32, _i32]),
     "lic_pack_weight_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _vp]),
     "lic_igemm_bf16": (C.c_int, [C.POINTER(IgemmDesc), _i32, _vp]),
+    "lic_igemm_bf16_kernel_name": (C.c_int, [C.POINTER(IgemmDesc), C.c_char_p, _sz]),
+    "lic_wgrad_bf16_kernel_name": (C.c_int, [C.POINTER(WgradDesc), C.c_char_p, _sz]),
     "lic_wgrad_bf16_workspace_bytes": (_sz, [C.POINTER(WgradDesc)]),
     "lic_wgrad_bf16": (C.c_int, [C.POINTER(WgradDesc), _vp, _sz, _vp]),
     "lic_im2col_bf16": (C.c_int, [_vp, _vp] + [_i32] * 11 + [_vp]),

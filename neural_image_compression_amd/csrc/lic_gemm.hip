@@ -1116,7 +1116,12 @@ static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& 
     }
   BM = cand[best][0];
   TN = cand[best][1];
-  if (const char* e = getenv("LIC_IGEMM_FORCE_TILE")) {  // tuning aid: "bm,tn"
+  if (d->force_bm || d->force_tn) {  // descriptor override (parity tests, the entropy coder's pinned variant)
+    const int fb = d->force_bm, ft = d->force_tn;
+    if (!((fb == 64 || fb == 128) && ft >= 1 && ft <= 3 && p.vec && p.Npad % (64 * ft) == 0)) return LIC_ERR_UNSUPPORTED;
+    BM = fb;
+    TN = ft;
+  } else if (const char* e = getenv("LIC_IGEMM_FORCE_TILE")) {  // tuning aid: "bm,tn"
     int fb = 0, ft = 0;
     if (sscanf(e, "%d,%d", &fb, &ft) == 2 && (fb == 64 || fb == 128) && ft >= 1 && ft <= 3 && p.vec &&
         p.Npad % (64 * ft) == 0) {
@@ -1163,11 +1168,14 @@ static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& 
   // The split factor depends only on per-image geometry (never on the batch size), so an image's
   // result does not depend on which batch it is computed in (bitwise batch-split invariance).
   const long t_img = (((long)d->Ho * d->Wo + 63) / 64) * ((p.Npad + 63) / 64);
-  if (simple_epi && !fuse && d->workspace && (t_img < 40 || getenv("LIC_IGEMM_FORCE_SPLIT")) && max_chunks >= 16) {
+  const char* env_split = d->force_split > 0 ? nullptr : getenv("LIC_IGEMM_FORCE_SPLIT");
+  if (simple_epi && !fuse && d->workspace && (t_img < 40 || env_split || d->force_split > 1) && d->force_split != 1 &&
+      (max_chunks >= 16 || d->force_split > 1)) {
     long S = (40 + t_img - 1) / t_img;
     if (S > max_chunks / 8) S = max_chunks / 8;  // at least 8 chunks per split
     if (S > 32) S = 32;
-    if (const char* e = getenv("LIC_IGEMM_FORCE_SPLIT")) S = atoi(e);  // tuning aid
+    if (env_split) S = atoi(env_split);  // tuning aid
+    if (d->force_split > 1) S = d->force_split < max_chunks ? d->force_split : max_chunks;
     if (S > 1) {
       p.cps = (int)((max_chunks + S - 1) / S);
       p.ksplit = (max_chunks + p.cps - 1) / p.cps;
@@ -1732,6 +1740,16 @@ static int wg_plan(const lic_wgrad_desc* d, WgPlan* pl) {
     pl->TM = 3;
     pl->TN = 3;
   }
+  if (d->force_tm || d->force_tn) {  // descriptor override: one of the instantiated shapes
+    const int tm = d->force_tm, tn = d->force_tn;
+    const bool sq_row = d->g_is_row ? d->sq_g : d->sq_p;
+    const bool t33 = tm == 3 && tn == 3 && pl->Cm % 192 == 0 && pl->Cn % 192 == 0 && !sq_row &&
+                     getenv("LIC_WGRAD_NO_GLDS") == nullptr;
+    const bool listed = (tm == 1 && (tn == 1 || tn == 3)) || (tm == 2 && tn >= 1 && tn <= 3);
+    if (!pl->vec || !(t33 || listed)) return LIC_ERR_UNSUPPORTED;
+    pl->TM = tm;
+    pl->TN = tn;
+  }
   pl->MTt = (pl->Cm + 64 * pl->TM - 1) / (64 * pl->TM);
   pl->NTt = (pl->Cn + 64 * pl->TN - 1) / (64 * pl->TN);
   const long Ps = (long)d->B * d->Hs * d->Ws;
@@ -1755,6 +1773,7 @@ static int wg_plan(const lic_wgrad_desc* d, WgPlan* pl) {
   if (pl->TM >= 2) sk = lic_pick_splits(base, resident, max_sk);
   if (const char* e = getenv("LIC_WGRAD_SPLITS")) sk = atol(e) > 0 ? atol(e) : sk;  // tuning aid
   if (sk > max_sk) sk = max_sk;
+  if (d->force_split > 0) sk = d->force_split < pl->nchunks ? d->force_split : pl->nchunks;  // tests: any split
   pl->cps = (int)((pl->nchunks + sk - 1) / sk);
   pl->splitk = (pl->nchunks + pl->cps - 1) / pl->cps;
   return LIC_OK;

@@ -390,7 +390,8 @@ LIC_EXPORT int lic_pack_weight_bf16(const float* src, void* dst, int32_t taps, i
 
 // d uses the lic_igemm_desc layout; activation / aux / out2 pointers are bf16, `w` is the bf16
 // packed weight, bias is fp32; out is bf16 unless out_f32.
-LIC_EXPORT int lic_igemm_bf16(const lic_igemm_desc* d, int32_t out_f32, lic_stream_t stream) {
+// fills the kernel parameter block and picks the tile; returns LIC_OK, or 1 when there is nothing to launch
+static int igemmh_prepare(const lic_igemm_desc* d, int32_t out_f32, IgemmHParams& p, int& BM, int& TN, long& nwg) {
   if (!d || !d->in || !d->w || !d->out) return LIC_ERR_INVALID;
   if (d->B <= 0 || d->Hi <= 0 || d->Wi <= 0 || d->Cin <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout <= 0 ||
       d->kh <= 0 || d->kw <= 0)
@@ -409,7 +410,6 @@ LIC_EXPORT int lic_igemm_bf16(const lic_igemm_desc* d, int32_t out_f32, lic_stre
   if (!al16h(d->in) || !al16h(d->w) || !al16h(d->out) || !al16h(d->out2) || !al16h(d->aux) || !al16h(d->aux2) ||
       !al16h(d->aux3))
     return LIC_ERR_INVALID;
-  IgemmHParams p;
   p.in = (const bf16_t*)d->in;
   p.w = (const bf16_t*)d->w;
   p.bias = d->bias;
@@ -470,13 +470,18 @@ LIC_EXPORT int lic_igemm_bf16(const lic_igemm_desc* d, int32_t out_f32, lic_stre
       }
     p.ntaps[ph] = n;
   }
-  if (maxP <= 0) return LIC_OK;
+  if (maxP <= 0) return 1;
   if (maxP > 0x7FFFFFFFL / 2) return LIC_ERR_UNSUPPORTED;
   // N tile: the widest of 192 / 128 / 64 columns that divides Npad; M tile: 128 rows while the grid
-  // keeps >= 512 workgroups
-  const int TN = (p.Npad % 192 == 0) ? 3 : ((p.Npad % 128 == 0) ? 2 : 1);
+  // keeps >= 512 workgroups (or the descriptor's force_bm: parity tests at small sizes)
+  TN = (p.Npad % 192 == 0) ? 3 : ((p.Npad % 128 == 0) ? 2 : 1);
   p.NT = p.Npad / (64 * TN);
-  const int BM = (((maxP + 127) / 128) * p.NT * p.nphase >= 512) ? 128 : 64;
+  BM = (((maxP + 127) / 128) * p.NT * p.nphase >= 512) ? 128 : 64;
+  if (d->force_bm) {
+    if (d->force_bm != 64 && d->force_bm != 128) return LIC_ERR_UNSUPPORTED;
+    BM = d->force_bm;
+  }
+  if (d->force_tn && d->force_tn != TN) return LIC_ERR_UNSUPPORTED;
   p.MT = (int)((maxP + BM - 1) / BM);
   p.pgroup = 0;
   p.porder = 0;
@@ -493,8 +498,29 @@ LIC_EXPORT int lic_igemm_bf16(const lic_igemm_desc* d, int32_t out_f32, lic_stre
     p.pgroup = 64;
     p.MT = ((p.MT + 63) / 64) * 64;
   }
-  const long nwg = (long)p.MT * p.NT * p.nphase;
+  nwg = (long)p.MT * p.NT * p.nphase;
   if (nwg > 0x7FFFFFFFL) return LIC_ERR_UNSUPPORTED;
+  return LIC_OK;
+}
+
+LIC_EXPORT int lic_igemm_bf16_kernel_name(const lic_igemm_desc* d, char* buf, size_t n) {
+  IgemmHParams p;
+  int BM = 0, TN = 0;
+  long nwg = 0;
+  const int rc = igemmh_prepare(d, 0, p, BM, TN, nwg);
+  if (rc < 0) return rc;
+  if (!buf || n == 0) return LIC_ERR_INVALID;
+  snprintf(buf, n, "igemm_bf16_kernel<%d, %d, %s>", BM, TN, p.prologue == 1 ? "true" : "false");
+  return LIC_OK;
+}
+
+LIC_EXPORT int lic_igemm_bf16(const lic_igemm_desc* d, int32_t out_f32, lic_stream_t stream) {
+  IgemmHParams p;
+  int BM = 0, TN = 0;
+  long nwg = 0;
+  const int rc = igemmh_prepare(d, out_f32, p, BM, TN, nwg);
+  if (rc < 0) return rc;
+  if (rc == 1) return LIC_OK;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)nwg), block(256);
 #define LIC_IGEMMH_LAUNCH(bm, tn)                                                        \
@@ -804,6 +830,14 @@ LIC_EXPORT size_t lic_wgrad_bf16_workspace_bytes(const lic_wgrad_desc* d) {
   WgHPlan pl;
   if (wgh_plan(d, &pl) != LIC_OK) return 0;
   return (size_t)pl.splitk * pl.ntaps * pl.Cm * pl.Cn * sizeof(float);
+}
+LIC_EXPORT int lic_wgrad_bf16_kernel_name(const lic_wgrad_desc* d, char* buf, size_t n) {
+  WgHPlan pl;
+  const int rc = wgh_plan(d, &pl);
+  if (rc != LIC_OK) return rc;
+  if (!buf || n == 0) return LIC_ERR_INVALID;
+  snprintf(buf, n, "wgrad_bf16_kernel<%d, %d, %s>", pl.TM, pl.TN, (d->g_is_row ? d->sq_p : d->sq_g) ? "true" : "false");
+  return LIC_OK;
 }
 // p / g are bf16 activations; dst and the workspace are fp32
 LIC_EXPORT int lic_wgrad_bf16(const lic_wgrad_desc* d, void* workspace, size_t workspace_bytes,

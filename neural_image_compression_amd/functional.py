@@ -23,6 +23,13 @@ LIKELIHOOD_BOUND = 1e-9
 # every MFMA launch; HIP events are recorded on the stream the kernels are launched on.
 PROFILE = None           # list -> every MFMA launch appends (kernel name, FLOP, bytes, start event, end event)
 PROFILE_MIN_FLOP = 0.0   # launches below this many algorithmic FLOP are not bracketed (event overhead)
+# Launch-plan overrides written into every descriptor (lic.h: force_bm / force_tn / force_split and
+# force_tm / force_tn / force_split; None = automatic).  The automatic tile depends on the batch, so the
+# parity tests use these to run every variant the full-size workloads dispatch against the oracle at small
+# sizes; codec.py pins one variant so encoder and decoder build identical tables.
+FORCE_IGEMM = None       # (bm, tn, split) -- 0 entries stay automatic
+FORCE_WGRAD = None       # (tm, tn, split)
+KERNEL_TRACE = None      # set -> the rocprofv3 name of every MFMA kernel variant launched is added
 
 
 # ------------------------------------------------------------------------------------------
@@ -117,6 +124,10 @@ def _igemm(inp, w_packed, out, *, B, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, 
     lib = L.load()
     ws = None
     fused = epilogue in (L.EPI_CONV_GDN, L.EPI_CONV_IGDN)
+    if FORCE_IGEMM is not None:
+        d.force_bm, d.force_tn, d.force_split = FORCE_IGEMM
+    if KERNEL_TRACE is not None:
+        KERNEL_TRACE.add(_kernel_name(lib.lic_igemm_kernel_name, d))
     if Ho * Wo <= 1024 and out2 is None and res is None:  # latent-side layers: allow split-K
         nbytes = lib.lic_igemm_workspace_bytes(C.byref(d))
         if nbytes:
@@ -141,6 +152,12 @@ def _igemm(inp, w_packed, out, *, B, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, 
     PROFILE.append((nm.value.decode(), flops, act_bytes, e0, e1))
 
 
+def _kernel_name(fn, d) -> str:
+    nm = C.create_string_buffer(96)
+    L.check(fn(C.byref(d), nm, 96), "kernel_name")
+    return nm.value.decode()
+
+
 def _timed(name, flops, act_bytes, launch):
     """run `launch()`; bracket it with HIP events when bench.py's PROFILE list is active"""
     if PROFILE is None or flops < PROFILE_MIN_FLOP:
@@ -163,6 +180,10 @@ def _wgrad(p, g, dst, *, B, Hs, Ws, Cp, Hl, Wl, Cg, kh, kw, stride, pad, g_is_ro
     d.kh, d.kw, d.stride, d.pad = kh, kw, stride, pad
     d.g_is_row, d.sq_p, d.sq_g, d.scale = int(g_is_row), sq_p, sq_g, scale
     lib = L.load()
+    if FORCE_WGRAD is not None:
+        d.force_tm, d.force_tn, d.force_split = FORCE_WGRAD
+    if KERNEL_TRACE is not None:
+        KERNEL_TRACE.add(_kernel_name(lib.lic_wgrad_kernel_name, d))
     nbytes = lib.lic_wgrad_workspace_bytes(C.byref(d))
     ws = torch.empty((max(nbytes, 4) + 3) // 4, device=p.device, dtype=torch.float32)
     if PROFILE is None or 2.0 * B * Hs * Ws * kh * kw * Cp * Cg < PROFILE_MIN_FLOP:
@@ -540,6 +561,8 @@ class _GDNFn(torch.autograd.Function):
         resh = None if res is None else _nhwc(res)
         P = B * H * W
         if lib.lic_gdn_supported(Cc):
+            if KERNEL_TRACE is not None:
+                KERNEL_TRACE.add(f"gdn_kernel<{Cc // 64}, {int(inverse)}>")
             _timed(f"gdn_kernel<{Cc // 64}, 0>", 2 * P * Cc * Cc, 4 * 3 * P * Cc,
                    lambda: L.check(lib.lic_gdn_fwd(_ptr(xh), _ptr(gT), _ptr(beta_e), _ptr(resh), _ptr(out), _ptr(norm),
                                                    P, Cc, int(inverse), _stream()), "lic_gdn_fwd"))
@@ -596,6 +619,8 @@ def _gdn_backward(xh, norm, gamma_e, beta_c, gamma_c, g, inverse, beta_bound, ga
         rows = lib.lic_gdn_bwd_partial_rows(P)
         pt = torch.empty((rows, Cc), device=xh.device, dtype=torch.float32)
         pdx = torch.empty((rows, Cc), device=xh.device, dtype=torch.float32)
+        if KERNEL_TRACE is not None:
+            KERNEL_TRACE.add(f"gdn_bwd_kernel<{Cc // 64}, {int(inverse)}>")
         _timed(f"gdn_bwd_reg_kernel<{Cc // 64}>", 2 * P * Cc * Cc, 4 * 5 * P * Cc,
                lambda: L.check(lib.lic_gdn_bwd(_ptr(g), _ptr(xh), _ptr(norm), _ptr(gp), _ptr(dxh), _ptr(t), _ptr(pt),
                                                _ptr(pdx), P, Cc, int(inverse), _stream()), "lic_gdn_bwd"))

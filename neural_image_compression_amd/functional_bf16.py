@@ -63,6 +63,10 @@ def _igemm_bf16(inp, w_packed, out, *, B, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, str
     d.transposed, d.prologue, d.epilogue = int(transposed), prologue, epilogue
     d.tap_mask, d.slope = 0, 0.01
     from . import functional as F_
+    if F_.FORCE_IGEMM is not None:
+        d.force_bm = F_.FORCE_IGEMM[0]  # the N tile follows from the channel count on this path
+    if F_.KERNEL_TRACE is not None:
+        F_.KERNEL_TRACE.add(F_._kernel_name(L.load().lic_igemm_bf16_kernel_name, d))
     if F_.PROFILE is None or 2.0 * B * Ho * Wo * Cout * Cin * kh * kw < F_.PROFILE_MIN_FLOP:
         L.check(L.load().lic_igemm_bf16(C.byref(d), int(out.dtype == torch.float32), _stream()), "lic_igemm_bf16")
         return
@@ -91,6 +95,8 @@ def _wgrad_bf16(p, g, dst, *, B, Hs, Ws, Cp, Hl, Wl, Cg, kh, kw, stride, pad, g_
     nbytes = lib.lic_wgrad_bf16_workspace_bytes(C.byref(d))
     ws = torch.empty((max(nbytes, 4) + 3) // 4, device=p.device, dtype=torch.float32)
     from . import functional as F_
+    if F_.KERNEL_TRACE is not None:
+        F_.KERNEL_TRACE.add(F_._kernel_name(lib.lic_wgrad_bf16_kernel_name, d))
     if F_.PROFILE is None or 2.0 * B * Hs * Ws * kh * kw * Cp * Cg < F_.PROFILE_MIN_FLOP:
         L.check(lib.lic_wgrad_bf16(C.byref(d), _ptr(ws), nbytes, _stream()), "lic_wgrad_bf16")
         return

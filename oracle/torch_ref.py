@@ -223,6 +223,36 @@ def step(state: Dict[str, "object"], x, M, K, kind="5x5", noise=None, lambda_rd=
 
 
 # ----------------------------------------------------------------------------------------------
+# single layers (Components.py:12,41 at their real sizes: tests/test_gpu_variants.py)
+# ----------------------------------------------------------------------------------------------
+def _np(a):
+    import numpy as np
+    return torch.as_tensor(np.ascontiguousarray(a))
+
+
+def conv2d_step(x, w, b, dy, stride, pad):
+    """nn.Conv2d forward + the three gradients for the output gradient `dy`; numpy in, numpy out."""
+    xt, wt, bt = _np(x).requires_grad_(True), _np(w).requires_grad_(True), _np(b).requires_grad_(True)
+    y = F.conv2d(xt, wt, bt, stride=stride, padding=pad)
+    y.backward(_np(dy))
+    return y.detach().numpy(), xt.grad.numpy(), wt.grad.numpy(), bt.grad.numpy()
+
+
+def conv_transpose2d(x, w, b, stride, pad, out_pad):
+    with torch.no_grad():
+        return F.conv_transpose2d(_np(x), _np(w), None if b is None else _np(b), stride=stride, padding=pad,
+                                  output_padding=out_pad).numpy()
+
+
+def conv_transpose2d_step(x, w, b, dy, stride, pad, out_pad):
+    """nn.ConvTranspose2d forward + the three gradients; numpy in, numpy out."""
+    xt, wt, bt = _np(x).requires_grad_(True), _np(w).requires_grad_(True), _np(b).requires_grad_(True)
+    y = F.conv_transpose2d(xt, wt, bt, stride=stride, padding=pad, output_padding=out_pad)
+    y.backward(_np(dy))
+    return y.detach().numpy(), xt.grad.numpy(), wt.grad.numpy(), bt.grad.numpy()
+
+
+# ----------------------------------------------------------------------------------------------
 # MS-SSIM (SURVEY 8(f).1).  The reference calls `pytorch_msssim.ms_ssim(recon, orig, data_range=1.0,
 # size_average=True)` (Evaluator.py:7,38,45; requirements.txt:5 pins pytorch-msssim==0.2.1, which is
 # not installable offline => PARITY UNPINNED).  Restated from the package's published algorithm.

@@ -41,7 +41,7 @@ def test_header_symbols_all_exported_and_bound(lib):
 
 def test_load_and_version(lib):
     L = lib.load()
-    assert L.lic_version() == 2
+    assert L.lic_version() == 3
     assert L.lic_arch() == b"gfx950"
 
 
