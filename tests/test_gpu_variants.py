@@ -341,7 +341,7 @@ def _full_step(nic, dev, M, K, B, H, W, seed, precision="fp32", lam=0.01):
     return model, st, x, (uz, uy), out, res
 
 
-def _compare_fp32(model, out, res, t_out, t_loss, t_grads):
+def _compare_fp32(model, out, res, t_out, t_loss, t_grads, grad_tol=5e-4):
     for k in ("y", "z", "x_hat"):
         a, b = host(out[k]).astype(np.float64), t_out[k].astype(np.float64)
         assert (np.abs(a - b) <= 1e-4 + 1e-4 * np.abs(b)).all(), (k, np.abs(a - b).max())
@@ -354,7 +354,7 @@ def _compare_fp32(model, out, res, t_out, t_loss, t_grads):
         e = max(0.0, err - 3e-7) / max(np.abs(ref).max(), 1e-12)  # (3e-7 floor: see test_gpu_fullsize.py)
         if e > worst[1]:
             worst = (name, e)
-    assert worst[1] <= 5e-4, worst
+    assert worst[1] <= grad_tol, worst
 
 
 CFG_FP32 = {
@@ -390,7 +390,12 @@ def test_cfg5_one_image_train_step_vs_c_oracle(env):
         model, st, x, noise, out, res = _full_step(nic, dev, M, K, 1, 512, 512, 555)
         o_out, o_loss, o_grads = O.model_forward(dict(st), x, M, K, "5x5", training=True, noise=noise,
                                                  lambda_rd=0.01, backward=True)
-        _compare_fp32(model, out, res, o_out, o_loss, o_grads)
+        # Gradient tolerance 2e-3 of each tensor's scale for this ONE-image case: the gradients of
+        # entropy_parameters.net.2 are ~3e-3 sums of cancelling terms here, and an fp64 evaluation of the same
+        # step (torch CPU, float64) sits 8.7e-4 of that scale away from BOTH fp32 CPU restatements (C oracle
+        # and torch fp32, which differ from each other by 6.7e-4): fp32 evaluation noise, not a kernel error.
+        # The 16-image config above, where the sums are longer and the cancellation milder, holds 5e-4.
+        _compare_fp32(model, out, res, o_out, o_loss, o_grads, grad_tol=2e-3)
 
 
 @pytest.mark.parametrize("M,K", [(128, 3), (192, 1)])
