@@ -351,6 +351,43 @@ size_t lic_tensor_stats_workspace_bytes(void);
 int lic_tensor_stats(const float* x, int64_t n, int32_t nbins, float lo, float hi, double* stats,
                      uint64_t* hist, void* workspace, size_t workspace_bytes, lic_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * lic_prep -- every parameter-derived buffer of a model refreshed by ONE launch per optimizer step.
+ *   The reference keeps derived values implicit in ATen (cuDNN/oneDNN repack weights internally; compressai's
+ *   GDN recomputes beta/gamma re-parametrisations in every forward, Components.py:11-44; ContextModels.py:19
+ *   masks the weight in place in every forward).  Here they are explicit buffers: the packed MFMA operand
+ *   of every conv / convT weight for the forward and for the data gradient (lic_pack_weight /
+ *   lic_pack_weight_bf16 layouts), beta_eff and the two packed gamma_eff panels of every GDN, the
+ *   column-matrix forms of the RGB stem / head weights.  A job describes one buffer:
+ *     PACK_F32 / PACK_BF16: dst = packed operand of the logical [taps][K][N] tensor whose element (tap, k, n)
+ *       is value(src[tap*s_tap + koff(k) + noff(n)]), koff(k) = kdiv ? (k/kdiv)*s_kq + (k%kdiv)*s_kr : k*s_kq
+ *       (same for n): the split index expresses the (tap, channel) <-> column maps of the RGB layers;
+ *     MAP: dst[i] = value(src[i]), i < N;   MASK_INPLACE: src[i] *= mask[i], i < N (ContextModels.py:19);
+ *     value(v) = v * mask (when `mask` is set, same offset as src), then transform 1 = the GDN
+ *       re-parametrisation max(v, bound)^2 - pedestal (lic_gdn_reparam).
+ *   A pack job may read a tensor that a MASK_INPLACE job of the same launch is masking, provided it names the
+ *   same mask: mask values are 0 or 1, so w*m and (w*m)*m are the same float whichever the read observes.
+ *   Usage: fill jobs on the host, lic_prep_plan (fills the derived fields, returns the grid size), copy the
+ *   array to device memory once, then lic_prep_run once per optimizer step.  Results are bit-identical to
+ *   the stand-alone entry points.
+ * ------------------------------------------------------------------------------------------ */
+enum lic_prep_kind { LIC_PREP_PACK_F32 = 0, LIC_PREP_PACK_BF16 = 1, LIC_PREP_MAP = 2, LIC_PREP_MASK_INPLACE = 3 };
+typedef struct lic_prep_job {
+  const float* src;
+  void* dst;
+  const float* mask;
+  int64_t s_tap, s_kq, s_kr, s_nq, s_nr;
+  int32_t kind; /* enum lic_prep_kind */
+  int32_t taps, K, N, kdiv, ndiv;
+  int32_t transform; /* 0 none, 1 GDN re-parametrisation */
+  float bound, pedestal;
+  /* derived by lic_prep_plan */
+  int32_t cpt, npad, tiled, v4, block0, nblocks;
+  int64_t total;
+} lic_prep_job;
+int64_t lic_prep_plan(lic_prep_job* jobs, int32_t njobs);
+int lic_prep_run(const lic_prep_job* jobs_device, int32_t njobs, int64_t total_blocks, lic_stream_t stream);
+
 int lic_version(void);        /* LIC_ABI_VERSION */
 int lic_last_hip_error(void); /* hipError_t of the most recent failed launch on this thread */
 const char* lic_arch(void);   /* "gfx950" */

@@ -43,6 +43,18 @@ class WgradDesc(C.Structure):
                 ("force_tm", _i32), ("force_tn", _i32), ("force_split", _i32)]
 
 
+PREP_PACK_F32, PREP_PACK_BF16, PREP_MAP, PREP_MASK_INPLACE = range(4)
+
+
+class PrepJob(C.Structure):
+    _fields_ = [("src", _vp), ("dst", _vp), ("mask", _vp),
+                ("s_tap", _i64), ("s_kq", _i64), ("s_kr", _i64), ("s_nq", _i64), ("s_nr", _i64),
+                ("kind", _i32), ("taps", _i32), ("K", _i32), ("N", _i32), ("kdiv", _i32), ("ndiv", _i32),
+                ("transform", _i32), ("bound", _f32), ("pedestal", _f32),
+                ("cpt", _i32), ("npad", _i32), ("tiled", _i32), ("v4", _i32), ("block0", _i32), ("nblocks", _i32),
+                ("total", _i64)]
+
+
 # name -> (restype, argtypes); every symbol declared in include/lic.h
 SIGNATURES = {
     "lic_igemm": (C.c_int, [C.POINTER(IgemmDesc), _vp]),
@@ -103,6 +115,8 @@ SIGNATURES = {
     "lic_u8_to_f32": (C.c_int, [_vp, _vp, _i64, _vp]),
     "lic_tensor_stats_workspace_bytes": (_sz, []),
     "lic_tensor_stats": (C.c_int, [_vp, _i64, _i32, _f32, _f32, _vp, _vp, _vp, _sz, _vp]),
+    "lic_prep_plan": (_i64, [C.POINTER(PrepJob), _i32]),
+    "lic_prep_run": (C.c_int, [_vp, _i32, _i64, _vp]),
     "lic_version": (C.c_int, []),
     "lic_last_hip_error": (C.c_int, []),
     "lic_arch": (C.c_char_p, []),

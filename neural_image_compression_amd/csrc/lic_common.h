@@ -35,6 +35,13 @@ __device__ __forceinline__ float lic_softplus(float v) { return v > 20.0f ? v : 
 __device__ __forceinline__ float lic_sigmoid(float v) { return 1.0f / (1.0f + expf(-v)); }
 __device__ __forceinline__ float lic_softplus_grad(float v) { return v > 20.0f ? 1.0f : lic_sigmoid(v); }
 
+// compressai NonNegativeParametrizer forward: LowerBound(p, bound)^2 - pedestal.
+// One definition for lic_gdn_reparam and lic_prep's transform, so both produce the same bits.
+__device__ __forceinline__ float lic_reparam(float p, float bound, float pedestal) {
+  const float v = p > bound ? p : bound;
+  return v * v - pedestal;
+}
+
 // wave64 sum via DPP-free shuffles
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -283,10 +283,7 @@ LIC_EXPORT int lic_leaky_bwd(const float* y, const float* dy, float* dx, int64_t
 LIC_EXPORT int lic_gdn_reparam(const float* p, float* out, int64_t n, float bound, float pedestal,
                                lic_stream_t stream) {
   if (!p || !out || n < 0) return LIC_ERR_INVALID;
-  return ew_launch(n, stream, [=] __device__(long i) {
-    const float v = p[i] > bound ? p[i] : bound;
-    out[i] = v * v - pedestal;
-  });
+  return ew_launch(n, stream, [=] __device__(long i) { out[i] = lic_reparam(p[i], bound, pedestal); });
 }
 LIC_EXPORT int lic_gdn_reparam_bwd(const float* p, const float* dout, float* dp, int64_t n, float bound,
                                    lic_stream_t stream) {

@@ -155,7 +155,8 @@ class MaskedConv2d(Conv2d):
         self._tap_mask = live
 
     def forward(self, x: Tensor) -> Tensor:
-        F_.mask_weight_(self.weight, self.mask)
+        if F_.prepared(self.weight, "masked") is None:  # else this step's lic_prep_run already masked it in place
+            F_.mask_weight_(self.weight, self.mask)
         s, p = self.stride[0], self.padding[0]
         return F_.conv2d(x, self.weight, self.bias, s, p, False, 0.01, self._tap_mask)
 

@@ -30,6 +30,12 @@ PROFILE_MIN_FLOP = 0.0   # launches below this many algorithmic FLOP are not bra
 FORCE_IGEMM = None       # (bm, tn, split) -- 0 entries stay automatic
 FORCE_WGRAD = None       # (tm, tn, split)
 KERNEL_TRACE = None      # set -> the rocprofv3 name of every MFMA kernel variant launched is added
+# id(parameter) -> (weakref, persistent gradient slot inside a data-parallel all-reduce bucket)
+# (parallel.GradientAllReducer); the weight-gradient kernels then write straight into the bucket
+GRAD_VIEWS = {}
+# (id(parameter), kind) -> (parameter version, derived buffer, weakref): packed weights, GDN re-parametrisations
+# ... refreshed once per optimizer step by prep.StepPrep (one lic_prep_run launch); see `prepared`
+PREPARED = {}
 
 
 # ------------------------------------------------------------------------------------------
@@ -92,6 +98,9 @@ def _pack_dense(m: torch.Tensor) -> torch.Tensor:
 def _pack_conv_weight(w: torch.Tensor, transposed_weight: bool, for_dgrad: bool) -> torch.Tensor:
     """`transposed_weight`: w is [Cin,Cout,kh,kw] (ConvTranspose2d), else [Cout,Cin,kh,kw].
     Forward contracts over the layer's input channels, dgrad over its output channels."""
+    hit = prepared(w, "f32.dgrad" if for_dgrad else "f32.fwd")
+    if hit is not None:
+        return hit
     w = w.contiguous()
     d0, d1, kh, kw = w.shape
     taps = kh * kw
@@ -210,6 +219,26 @@ def _colsum(t2d: torch.Tensor, P: int, Cc: int, scale: float = 1.0) -> torch.Ten
     return out
 
 
+def prepared(param: torch.Tensor, kind: str):
+    """The buffer of `kind` that prep.StepPrep derived from `param`, if it was built from the parameter's
+    current version (optimizer.step() bumps the version; autograd hands backward the same Parameter object
+    it saw in forward); None -> the caller derives it on the fly."""
+    e = PREPARED.get((id(param), kind))
+    if e is not None and e[0] == param._version and e[2]() is param:
+        return e[1]
+    return None
+
+
+def grad_like(param: torch.Tensor) -> torch.Tensor:
+    """Destination for `param`'s gradient: its slot in the all-reduce bucket when data parallelism registered one
+    and no gradient has been accumulated yet this step (autograd then adopts the slot as `.grad` without a
+    copy), else a fresh contiguous tensor."""
+    e = GRAD_VIEWS.get(id(param)) if GRAD_VIEWS else None
+    if e is not None and e[0]() is param and param.grad is None:
+        return e[1]
+    return torch.empty_like(param, memory_format=torch.contiguous_format)
+
+
 def _leaky_bwd(y, dy, slope):
     dx = torch.empty_like(y)
     L.check(L.load().lic_leaky_bwd(_ptr(y), _ptr(dy), _ptr(dx), y.numel(), slope, _stream()),
@@ -281,7 +310,7 @@ def _conv_backward(xh, weight, g, stride, pad, transposed, tap_mask, need_dx, ne
                stride=stride, pad=pad, transposed=not transposed, tap_mask=tap_mask)
         dx = _nchw_view(dxh)
     if need_dw:
-        dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+        dw = grad_like(weight)
         taps = kh * kw
         if transposed:  # weight [Cin,Cout,kh,kw]; small grid = input, gathered = grad
             _wgrad(xh, g, dw, B=B, Hs=Hi, Ws=Wi, Cp=Cin, Hl=Ho, Wl=Wo, Cg=Cout, kh=kh, kw=kw,
@@ -341,7 +370,7 @@ def _kpad(kh, kw, c):
 
 
 def _image_conv_columns(xh, weight, stride, pad):
-    """im2col of the few-channel input + the [Kp][Cout] weight matrix; returns (col, wp, Ho, Wo, Kp)."""
+    """im2col of the few-channel input + the packed [Kp][Cout] weight matrix; returns (col, wp_packed, Ho, Wo, Kp)."""
     B, Hi, Wi, Cin = xh.shape
     Cout, _, kh, kw = weight.shape
     Ho, Wo = conv_out_size(Hi, Wi, kh, stride, pad, False)
@@ -351,10 +380,13 @@ def _image_conv_columns(xh, weight, stride, pad):
     L.check(L.load().lic_im2col(_ptr(xh), _ptr(col), B, Hi, Wi, Cin, Ho, Wo, kh, kw, stride, pad, Kp,
                                 _stream()), "lic_im2col")
     taps = kh * kw
-    wp = torch.zeros((Kp, Cout), device=xh.device, dtype=torch.float32)
-    # wp[tap*Cin + c][co] = w[co][c][tap]
-    _permute3(weight.contiguous(), wp, (taps, Cin, Cout), (1, taps, Cin * taps), (Cin * Cout, Cout, 1))
-    return col, wp, Ho, Wo, Kp
+    wpk = prepared(weight, "f32.stem")
+    if wpk is None:
+        wp = torch.zeros((Kp, Cout), device=xh.device, dtype=torch.float32)
+        # wp[tap*Cin + c][co] = w[co][c][tap]
+        _permute3(weight.contiguous(), wp, (taps, Cin, Cout), (1, taps, Cin * taps), (Cin * Cout, Cout, 1))
+        wpk = _pack_dense(wp)
+    return col, wpk, Ho, Wo, Kp
 
 
 def _image_conv_backward(col, weight, g, stride, pad, in_shape, need_dx, need_dw, need_db):
@@ -378,7 +410,7 @@ def _image_conv_backward(col, weight, g, stride, pad, in_shape, need_dx, need_dw
         tmp = torch.empty((Kp, Cout), device=g.device, dtype=torch.float32)
         _wgrad(col, g, tmp, B=1, Hs=1, Ws=P, Cp=Kp, Hl=1, Wl=P, Cg=Cout, kh=1, kw=1, stride=1, pad=0,
                g_is_row=False, dst_sm=Cout, dst_sn=1, dst_stap=0)
-        dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+        dw = grad_like(weight)
         _permute3(tmp, dw, (taps, Cin, Cout), (Cin * Cout, Cout, 1), (1, taps, Cin * taps))
     if need_db:
         db = _bias_grad(g, P, Cout)
@@ -398,7 +430,7 @@ class _ImageConvFn(torch.autograd.Function):
         col, wp, Ho, Wo, Kp = _image_conv_columns(xh, weight, stride, pad)
         P = B * Ho * Wo
         out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
-        _igemm(col, _pack_dense(wp), out, B=1, Hi=1, Wi=P, Cin=Kp, Ho=1, Wo=P, Cout=Cout, kh=1, kw=1, stride=1,
+        _igemm(col, wp, out, B=1, Hi=1, Wi=P, Cin=Kp, Ho=1, Wo=P, Cout=Cout, kh=1, kw=1, stride=1,
                pad=0, transposed=False, bias=bias, epilogue=L.EPI_LEAKY if leaky else L.EPI_NONE,
                slope=slope)
         ctx.save_for_backward(col, weight, out if leaky else None)
@@ -430,25 +462,24 @@ class _ImageConvGDNFn(torch.autograd.Function):
         Cout = weight.shape[0]
         col, wp, Ho, Wo, Kp = _image_conv_columns(xh, weight, stride, pad)
         P = B * Ho * Wo
-        beta_c, gamma_c, beta_e, gamma_e = _gdn_reparam(beta, gamma, beta_bound, gamma_bound, pedestal)
-        gT = _pack(gamma_e, 1, Cout, Cout, 0, 1, Cout)
+        beta_e, gT = _gdn_operands(beta, gamma, beta_bound, gamma_bound, pedestal)
         conv_out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
         norm = torch.empty_like(conv_out)
         y = torch.empty_like(conv_out)
-        _igemm(col, _pack_dense(wp), y, B=1, Hi=1, Wi=P, Cin=Kp, Ho=1, Wo=P, Cout=Cout, kh=1, kw=1, stride=1,
+        _igemm(col, wp, y, B=1, Hi=1, Wi=P, Cin=Kp, Ho=1, Wo=P, Cout=Cout, kh=1, kw=1, stride=1,
                pad=0, transposed=False, bias=bias, epilogue=L.EPI_CONV_IGDN if inverse else L.EPI_CONV_GDN,
                out2=norm, out3=conv_out, aux=gT, aux2=beta_e)
-        ctx.save_for_backward(col, weight, conv_out, norm, gamma_e, beta_c, gamma_c)
-        ctx.cfg = (stride, pad, tuple(xh.shape), inverse, beta_bound, gamma_bound, bias is not None)
+        ctx.save_for_backward(col, weight, conv_out, norm, beta, gamma)
+        ctx.cfg = (stride, pad, tuple(xh.shape), inverse, beta_bound, gamma_bound, bias is not None, pedestal)
         return _nchw_view(y)
 
     @staticmethod
     def backward(ctx, gy):
-        col, weight, conv_out, norm, gamma_e, beta_c, gamma_c = ctx.saved_tensors
-        stride, pad, in_shape, inverse, beta_bound, gamma_bound, has_bias = ctx.cfg
+        col, weight, conv_out, norm, beta, gamma = ctx.saved_tensors
+        stride, pad, in_shape, inverse, beta_bound, gamma_bound, has_bias, pedestal = ctx.cfg
         need = ctx.needs_input_grad
-        g_conv, dbeta, dgamma = _gdn_backward(conv_out, norm, gamma_e, beta_c, gamma_c, _nhwc(gy), inverse,
-                                              beta_bound, gamma_bound, True, need[3], need[4])
+        g_conv, dbeta, dgamma = _gdn_backward(conv_out, norm, beta, gamma, _nhwc(gy), inverse,
+                                              beta_bound, gamma_bound, pedestal, True, need[3], need[4])
         dx, dw, db = _image_conv_backward(col, weight, g_conv, stride, pad, in_shape, need[0], need[1],
                                           has_bias and need[2])
         return dx, dw, db, dbeta, dgamma, None, None, None, None, None, None
@@ -467,11 +498,14 @@ class _ImageConvTFn(torch.autograd.Function):
         Ho, Wo = conv_out_size(Hi, Wi, kh, stride, pad, True, out_pad)
         taps, Kp, P = kh * kw, _kpad(kh, kw, Cout), B * Hi * Wi
         lib = L.load()
-        wp = torch.zeros((Cin, Kp), device=x.device, dtype=torch.float32)
-        # wp[ci][tap*Cout + co] = w[ci][co][tap]
-        _permute3(weight.contiguous(), wp, (Cin, Cout, taps), (Cout * taps, taps, 1), (Kp, 1, Cout))
+        wpk = prepared(weight, "f32.head")
+        if wpk is None:
+            wp = torch.zeros((Cin, Kp), device=x.device, dtype=torch.float32)
+            # wp[ci][tap*Cout + co] = w[ci][co][tap]
+            _permute3(weight.contiguous(), wp, (Cin, Cout, taps), (Cout * taps, taps, 1), (Kp, 1, Cout))
+            wpk = _pack_dense(wp)
         col = torch.empty((P, Kp), device=x.device, dtype=torch.float32)
-        _igemm(xh, _pack_dense(wp), col, B=1, Hi=1, Wi=P, Cin=Cin, Ho=1, Wo=P, Cout=Kp, kh=1, kw=1, stride=1, pad=0,
+        _igemm(xh, wpk, col, B=1, Hi=1, Wi=P, Cin=Cin, Ho=1, Wo=P, Cout=Kp, kh=1, kw=1, stride=1, pad=0,
                transposed=False)
         out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
         L.check(lib.lic_col2im(_ptr(col), _ptr(bias), _ptr(out), B, Hi, Wi, Cout, Ho, Wo, kh, kw, stride,
@@ -494,18 +528,23 @@ class _ImageConvTFn(torch.autograd.Function):
                                _stream()), "lic_im2col")
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wpT = torch.zeros((Kp, Cin), device=g.device, dtype=torch.float32)
-            _permute3(weight.contiguous(), wpT, (taps, Cout, Cin), (1, taps, Cout * taps),
-                      (Cout * Cin, Cin, 1))
+            wpk = prepared(weight, "f32.head_dx")
+            if wpk is None:
+                wpT = torch.zeros((Kp, Cin), device=g.device, dtype=torch.float32)
+                _permute3(weight.contiguous(), wpT, (taps, Cout, Cin), (1, taps, Cout * taps),
+                          (Cout * Cin, Cin, 1))
+                wpk = _pack_dense(wpT)
             dxh = torch.empty_like(xh)
-            _igemm(dcol, _pack_dense(wpT), dxh, B=1, Hi=1, Wi=P, Cin=Kp, Ho=1, Wo=P, Cout=Cin, kh=1, kw=1, stride=1,
+            _igemm(dcol, wpk, dxh, B=1, Hi=1, Wi=P, Cin=Kp, Ho=1, Wo=P, Cout=Cin, kh=1, kw=1, stride=1,
                    pad=0, transposed=False)
             dx = _nchw_view(dxh)
         if ctx.needs_input_grad[1]:
             tmp = torch.empty((Cin, Kp), device=g.device, dtype=torch.float32)
+            # rows = the 80 columns of dcol, cols = the Cin channels of x: ONE 128x192 tile spans the whole product,
+            # so each operand is streamed once per split (x on the rows needed 3 x 2 tiles of 64x64: 378 -> ~200 us)
             _wgrad(xh, dcol, tmp, B=1, Hs=1, Ws=P, Cp=Cin, Hl=1, Wl=P, Cg=Kp, kh=1, kw=1, stride=1, pad=0,
-                   g_is_row=False, dst_sm=Kp, dst_sn=1, dst_stap=0)
-            dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+                   g_is_row=True, dst_sm=1, dst_sn=Kp, dst_stap=0)
+            dw = grad_like(weight)
             _permute3(tmp, dw, (Cin, taps, Cout), (Kp, Cout, 1), (Cout * taps, 1, taps))
         if has_bias and ctx.needs_input_grad[2]:
             db = _colsum(g, B * Ho * Wo, Cout)
@@ -554,8 +593,7 @@ class _GDNFn(torch.autograd.Function):
         lib = L.load()
         xh = _nhwc(x)
         B, H, W, Cc = xh.shape
-        beta_c, gamma_c, beta_e, gamma_e = _gdn_reparam(beta, gamma, beta_bound, gamma_bound, pedestal)
-        gT = _pack(gamma_e, 1, Cc, Cc, 0, 1, Cc)  # B operand [k=j][n=i] = gamma_e[i][j]
+        beta_e, gT = _gdn_operands(beta, gamma, beta_bound, gamma_bound, pedestal)
         out = torch.empty_like(xh)
         norm = torch.empty_like(xh)
         resh = None if res is None else _nhwc(res)
@@ -570,21 +608,45 @@ class _GDNFn(torch.autograd.Function):
             _igemm(xh, gT, out, B=1, Hi=1, Wi=P, Cin=Cc, Ho=1, Wo=P, Cout=Cc, kh=1, kw=1, stride=1, pad=0,
                    transposed=False, bias=beta_e, prologue=1, epilogue=L.EPI_IGDN if inverse else L.EPI_GDN,
                    out2=norm, aux=xh, res=resh)
-        ctx.save_for_backward(xh, norm, gamma_e, beta_c, gamma_c)
-        ctx.cfg = (inverse, beta_bound, gamma_bound, res is not None)
+        ctx.save_for_backward(xh, norm, beta, gamma)
+        ctx.cfg = (inverse, beta_bound, gamma_bound, res is not None, pedestal)
         return _nchw_view(out)
 
     @staticmethod
     def backward(ctx, gy):
-        xh, norm, gamma_e, beta_c, gamma_c = ctx.saved_tensors
-        inverse, beta_bound, gamma_bound, has_res = ctx.cfg
-        dxh, dbeta, dgamma = _gdn_backward(xh, norm, gamma_e, beta_c, gamma_c, _nhwc(gy), inverse, beta_bound,
-                                           gamma_bound, *ctx.needs_input_grad[:3])
+        xh, norm, beta, gamma = ctx.saved_tensors
+        inverse, beta_bound, gamma_bound, has_res, pedestal = ctx.cfg
+        dxh, dbeta, dgamma = _gdn_backward(xh, norm, beta, gamma, _nhwc(gy), inverse, beta_bound,
+                                           gamma_bound, pedestal, *ctx.needs_input_grad[:3])
         dres = gy if has_res else None
         dx = None if dxh is None else _nchw_view(dxh)
         if dx is not None and hasattr(dxh, "_lic_colsum_partial"):
             dx._lic_colsum_partial = dxh._lic_colsum_partial  # rides along to the producing conv's backward
         return dx, dbeta, dgamma, None, None, None, None, dres
+
+
+def _gdn_operands(beta, gamma, beta_bound, gamma_bound, pedestal):
+    """(beta_eff [C], packed gamma_eff^T: B operand [k = j][n = i] = gamma_eff[i][j]) of a GDN's forward pool:
+    from the step preparation when it is current, else derived here."""
+    beta_e, gT = prepared(beta, "f32.beta_e"), prepared(gamma, "f32.gdn_gT")
+    if beta_e is None or gT is None:
+        Cc = beta.numel()
+        _, _, beta_e, gamma_e = _gdn_reparam(beta, gamma, beta_bound, gamma_bound, pedestal)
+        gT = _pack(gamma_e, 1, Cc, Cc, 0, 1, Cc)
+    return beta_e, gT
+
+
+def _gdn_gamma_packed(gamma, gamma_bound, pedestal):
+    """packed gamma_eff (row-major [j][i]): the backward contraction t . gamma_eff"""
+    gp = prepared(gamma, "f32.gdn_g")
+    if gp is None:
+        lib = L.load()
+        gamma_c = gamma.contiguous()
+        gamma_e = torch.empty_like(gamma_c)
+        L.check(lib.lic_gdn_reparam(_ptr(gamma_c), _ptr(gamma_e), gamma_c.numel(), gamma_bound, pedestal, _stream()),
+                "lic_gdn_reparam")
+        gp = _pack_dense(gamma_e)
+    return gp
 
 
 def _gdn_reparam(beta, gamma, beta_bound, gamma_bound, pedestal):
@@ -601,7 +663,7 @@ def _gdn_reparam(beta, gamma, beta_bound, gamma_bound, pedestal):
     return beta_c, gamma_c, beta_e, gamma_e
 
 
-def _gdn_backward(xh, norm, gamma_e, beta_c, gamma_c, g, inverse, beta_bound, gamma_bound, need_dx, need_dbeta,
+def _gdn_backward(xh, norm, beta, gamma, g, inverse, beta_bound, gamma_bound, pedestal, need_dx, need_dbeta,
                   need_dgamma):
     """GDN / IGDN backward from the saved input x and pool `norm`; returns (dx NHWC, dbeta, dgamma)."""
     lib = L.load()
@@ -611,11 +673,12 @@ def _gdn_backward(xh, norm, gamma_e, beta_c, gamma_c, g, inverse, beta_bound, ga
     dxh = dbeta = dgamma = None
     cs_dx = None
     dbe = None
+    beta_c, gamma_c = beta.contiguous(), gamma.contiguous()
+    gp = _gdn_gamma_packed(gamma, gamma_bound, pedestal) if need_dx else None
     if need_dx and lib.lic_gdn_supported(Cc):
         # the dedicated one-sweep kernel: t built from (g, x, norm) as the tile is loaded; it also emits
         # per-workgroup column sums of t (-> d beta) and of dx (-> the d bias of the conv in front)
         dxh = torch.empty_like(xh)
-        gp = _pack_dense(gamma_e)
         rows = lib.lic_gdn_bwd_partial_rows(P)
         pt = torch.empty((rows, Cc), device=xh.device, dtype=torch.float32)
         pdx = torch.empty((rows, Cc), device=xh.device, dtype=torch.float32)
@@ -631,7 +694,7 @@ def _gdn_backward(xh, norm, gamma_e, beta_c, gamma_c, g, inverse, beta_bound, ga
         # one launch: t = dL/dnorm built on the fly as the contraction's operand (and stored for the
         # parameter gradients), dx = g * rsqrt(norm) + 2 x (t . gamma) in the epilogue
         dxh = torch.empty_like(xh)
-        _igemm(g, _pack_dense(gamma_e), dxh, B=1, Hi=1, Wi=P, Cin=Cc, Ho=1, Wo=P, Cout=Cc, kh=1, kw=1, stride=1,
+        _igemm(g, gp, dxh, B=1, Hi=1, Wi=P, Cin=Cc, Ho=1, Wo=P, Cout=Cc, kh=1, kw=1, stride=1,
                pad=0, transposed=False, prologue=3 if inverse else 2,
                epilogue=L.EPI_IGDN_BWD if inverse else L.EPI_GDN_BWD, aux=g, aux2=xh, aux3=norm, out2=t)
     else:
@@ -639,7 +702,7 @@ def _gdn_backward(xh, norm, gamma_e, beta_c, gamma_c, g, inverse, beta_bound, ga
                                   _stream()), "lic_gdn_dnorm")
         if need_dx:
             dxh = torch.empty_like(xh)
-            _igemm(t, _pack_dense(gamma_e), dxh, B=1, Hi=1, Wi=P, Cin=Cc, Ho=1, Wo=P, Cout=Cc, kh=1, kw=1,
+            _igemm(t, gp, dxh, B=1, Hi=1, Wi=P, Cin=Cc, Ho=1, Wo=P, Cout=Cc, kh=1, kw=1,
                    stride=1, pad=0, transposed=False, epilogue=L.EPI_IGDN_BWD if inverse else L.EPI_GDN_BWD,
                    aux=g, aux2=xh, aux3=norm)
     if need_dbeta:
@@ -649,7 +712,7 @@ def _gdn_backward(xh, norm, gamma_e, beta_c, gamma_c, g, inverse, beta_bound, ga
         L.check(lib.lic_gdn_reparam_bwd(_ptr(beta_c), _ptr(dbe), _ptr(dbeta), Cc, beta_bound,
                                         _stream()), "lic_gdn_reparam_bwd")
     if need_dgamma:
-        dge = torch.empty_like(gamma_e)
+        dge = torch.empty_like(gamma_c)
         _wgrad(t, xh, dge, B=1, Hs=1, Ws=P, Cp=Cc, Hl=1, Wl=P, Cg=Cc, kh=1, kw=1, stride=1, pad=0,
                g_is_row=False, dst_sm=Cc, dst_sn=1, dst_stap=0, sq_g=1)
         dgamma = torch.empty_like(gamma_c)
@@ -675,8 +738,7 @@ class _ConvGDNFn(torch.autograd.Function):
         Cout = weight.shape[1] if transposed else weight.shape[0]
         Ho, Wo = conv_out_size(Hi, Wi, kh, stride, pad, transposed, out_pad)
         wp = _pack_conv_weight(weight, transposed, for_dgrad=False)
-        beta_c, gamma_c, beta_e, gamma_e = _gdn_reparam(beta, gamma, beta_bound, gamma_bound, pedestal)
-        gT = _pack(gamma_e, 1, Cout, Cout, 0, 1, Cout)  # B operand [k=j][n=i] = gamma_e[i][j]
+        beta_e, gT = _gdn_operands(beta, gamma, beta_bound, gamma_bound, pedestal)
         conv_out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
         norm = torch.empty_like(conv_out)
         y = torch.empty_like(conv_out)
@@ -684,17 +746,17 @@ class _ConvGDNFn(torch.autograd.Function):
                pad=pad, transposed=transposed, bias=bias,
                epilogue=L.EPI_CONV_IGDN if inverse else L.EPI_CONV_GDN, out2=norm, out3=conv_out, aux=gT,
                aux2=beta_e)
-        ctx.save_for_backward(xh, weight, conv_out, norm, gamma_e, beta_c, gamma_c)
-        ctx.cfg = (stride, pad, transposed, inverse, beta_bound, gamma_bound, bias is not None)
+        ctx.save_for_backward(xh, weight, conv_out, norm, beta, gamma)
+        ctx.cfg = (stride, pad, transposed, inverse, beta_bound, gamma_bound, bias is not None, pedestal)
         return _nchw_view(y)
 
     @staticmethod
     def backward(ctx, gy):
-        xh, weight, conv_out, norm, gamma_e, beta_c, gamma_c = ctx.saved_tensors
-        stride, pad, transposed, inverse, beta_bound, gamma_bound, has_bias = ctx.cfg
+        xh, weight, conv_out, norm, beta, gamma = ctx.saved_tensors
+        stride, pad, transposed, inverse, beta_bound, gamma_bound, has_bias, pedestal = ctx.cfg
         need = ctx.needs_input_grad
-        g_conv, dbeta, dgamma = _gdn_backward(conv_out, norm, gamma_e, beta_c, gamma_c, _nhwc(gy), inverse,
-                                              beta_bound, gamma_bound, True, need[3], need[4])
+        g_conv, dbeta, dgamma = _gdn_backward(conv_out, norm, beta, gamma, _nhwc(gy), inverse,
+                                              beta_bound, gamma_bound, pedestal, True, need[3], need[4])
         dx, dw, db = _conv_backward(xh, weight, g_conv, stride, pad, transposed, 0, need[0], need[1],
                                     has_bias and need[2])
         return dx, dw, db, dbeta, dgamma, None, None, None, None, None, None, None, None

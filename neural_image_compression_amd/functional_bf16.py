@@ -13,7 +13,8 @@ import ctypes as C
 import torch
 
 from . import _lib as L
-from .functional import (PEDESTAL, _colsum, _nchw_view, _nhwc, _permute3, _ptr, _stream, conv_out_size)
+from .functional import (PEDESTAL, _colsum, _nchw_view, _nhwc, _permute3, _ptr, _stream, conv_out_size, grad_like,
+                         prepared)
 
 BF16 = torch.bfloat16
 
@@ -39,6 +40,9 @@ def _pack_bf16(src: torch.Tensor, taps, K, N, s_tap, s_k, s_n) -> torch.Tensor:
 
 
 def _pack_conv_weight_bf16(w, transposed_weight, for_dgrad):
+    hit = prepared(w, "bf16.dgrad" if for_dgrad else "bf16.fwd")
+    if hit is not None:
+        return hit
     w = w.contiguous()
     d0, d1, kh, kw = w.shape
     taps = kh * kw
@@ -154,7 +158,7 @@ class _ConvBF16Fn(torch.autograd.Function):
                         pad=pad, transposed=not transposed)
             dx = _nchw_view(dxh)
         if ctx.needs_input_grad[1]:
-            dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+            dw = grad_like(weight)
             if transposed:
                 _wgrad_bf16(xh, g, dw, B=B, Hs=Hi, Ws=Wi, Cp=Cin, Hl=Ho, Wl=Wo, Cg=Cout, kh=kh, kw=kw, stride=stride,
                             pad=pad, g_is_row=False, dst_sm=Cout * taps, dst_sn=taps, dst_stap=1)
@@ -187,10 +191,13 @@ class _ImageConvBF16Fn(torch.autograd.Function):
         col = torch.empty((P, Kp), device=x.device, dtype=BF16)
         L.check(lib.lic_im2col_bf16(_ptr(xh), _ptr(col), B, Hi, Wi, Cin, Ho, Wo, kh, kw, stride, pad, Kp, _stream()),
                 "lic_im2col_bf16")
-        wd = torch.zeros((Kp, Cout), device=x.device, dtype=torch.float32)
-        _permute3(weight.contiguous(), wd, (taps, Cin, Cout), (1, taps, Cin * taps), (Cin * Cout, Cout, 1))
+        wpk = prepared(weight, "bf16.stem")
+        if wpk is None:
+            wd = torch.zeros((Kp, Cout), device=x.device, dtype=torch.float32)
+            _permute3(weight.contiguous(), wd, (taps, Cin, Cout), (1, taps, Cin * taps), (Cin * Cout, Cout, 1))
+            wpk = _pack_bf16(wd, 1, Kp, Cout, 0, Cout, 1)
         out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=BF16)
-        _igemm_bf16(col, _pack_bf16(wd, 1, Kp, Cout, 0, Cout, 1), out, B=1, Hi=1, Wi=P, Cin=Kp, Ho=1, Wo=P, Cout=Cout,
+        _igemm_bf16(col, wpk, out, B=1, Hi=1, Wi=P, Cin=Kp, Ho=1, Wo=P, Cout=Cout,
                     kh=1, kw=1, stride=1, pad=0, transposed=False, bias=bias)
         ctx.save_for_backward(col, weight)
         ctx.cfg = (Cin, bias is not None)
@@ -209,7 +216,7 @@ class _ImageConvBF16Fn(torch.autograd.Function):
             tmp = torch.empty((Kp, Cout), device=g.device, dtype=torch.float32)
             _wgrad_bf16(col, g, tmp, B=1, Hs=1, Ws=P, Cp=Kp, Hl=1, Wl=P, Cg=Cout, kh=1, kw=1, stride=1, pad=0,
                         g_is_row=False, dst_sm=Cout, dst_sn=1, dst_stap=0)
-            dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+            dw = grad_like(weight)
             _permute3(tmp, dw, (taps, Cin, Cout), (Cin * Cout, Cout, 1), (1, taps, Cin * taps))
         if has_bias and ctx.needs_input_grad[2]:
             db = _colsum_bf16(g, P, Cout)
@@ -228,10 +235,13 @@ class _ImageConvTBF16Fn(torch.autograd.Function):
         Ho, Wo = conv_out_size(Hi, Wi, kh, stride, pad, True, out_pad)
         taps, Kp, P = kh * kw, _kpad8(kh, kw, Cout), B * Hi * Wi
         lib = L.load()
-        wd = torch.zeros((Cin, Kp), device=x.device, dtype=torch.float32)
-        _permute3(weight.contiguous(), wd, (Cin, Cout, taps), (Cout * taps, taps, 1), (Kp, 1, Cout))
+        wpk = prepared(weight, "bf16.head")
+        if wpk is None:
+            wd = torch.zeros((Cin, Kp), device=x.device, dtype=torch.float32)
+            _permute3(weight.contiguous(), wd, (Cin, Cout, taps), (Cout * taps, taps, 1), (Kp, 1, Cout))
+            wpk = _pack_bf16(wd, 1, Cin, Kp, 0, Kp, 1)
         col = torch.empty((P, Kp), device=x.device, dtype=BF16)
-        _igemm_bf16(xh, _pack_bf16(wd, 1, Cin, Kp, 0, Kp, 1), col, B=1, Hi=1, Wi=P, Cin=Cin, Ho=1, Wo=P, Cout=Kp,
+        _igemm_bf16(xh, wpk, col, B=1, Hi=1, Wi=P, Cin=Cin, Ho=1, Wo=P, Cout=Kp,
                     kh=1, kw=1, stride=1, pad=0, transposed=False)
         out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
         L.check(lib.lic_col2im_bf16(_ptr(col), _ptr(bias), _ptr(out), B, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, pad,
@@ -254,21 +264,32 @@ class _ImageConvTBF16Fn(torch.autograd.Function):
                 "lic_im2col_bf16")
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            wdT = torch.zeros((Kp, Cin), device=g.device, dtype=torch.float32)
-            _permute3(weight.contiguous(), wdT, (taps, Cout, Cin), (1, taps, Cout * taps), (Cout * Cin, Cin, 1))
+            wpk = prepared(weight, "bf16.head_dx")
+            if wpk is None:
+                wdT = torch.zeros((Kp, Cin), device=g.device, dtype=torch.float32)
+                _permute3(weight.contiguous(), wdT, (taps, Cout, Cin), (1, taps, Cout * taps), (Cout * Cin, Cin, 1))
+                wpk = _pack_bf16(wdT, 1, Kp, Cin, 0, Cin, 1)
             dxh = torch.empty((B, Hi, Wi, Cin), device=g.device, dtype=in_dtype)
-            _igemm_bf16(dcol, _pack_bf16(wdT, 1, Kp, Cin, 0, Cin, 1), dxh, B=1, Hi=1, Wi=P, Cin=Kp, Ho=1, Wo=P,
+            _igemm_bf16(dcol, wpk, dxh, B=1, Hi=1, Wi=P, Cin=Kp, Ho=1, Wo=P,
                         Cout=Cin, kh=1, kw=1, stride=1, pad=0, transposed=False)
             dx = _nchw_view(dxh)
         if ctx.needs_input_grad[1]:
             tmp = torch.empty((Cin, Kp), device=g.device, dtype=torch.float32)
             _wgrad_bf16(xh, dcol, tmp, B=1, Hs=1, Ws=P, Cp=Cin, Hl=1, Wl=P, Cg=Kp, kh=1, kw=1, stride=1, pad=0,
                         g_is_row=False, dst_sm=Kp, dst_sn=1, dst_stap=0)
-            dw = torch.empty_like(weight, memory_format=torch.contiguous_format)
+            dw = grad_like(weight)
             _permute3(tmp, dw, (Cin, taps, Cout), (Kp, Cout, 1), (Cout * taps, 1, taps))
         if has_bias and ctx.needs_input_grad[2]:
             db = _colsum(g, B * Ho * Wo, Cout)
         return dx, dw, db, None, None, None
+
+
+def _gamma_eff(gamma, gamma_bound, pedestal):
+    gamma_c = gamma.contiguous()
+    gamma_e = torch.empty_like(gamma_c)
+    L.check(L.load().lic_gdn_reparam(_ptr(gamma_c), _ptr(gamma_e), gamma_c.numel(), gamma_bound, pedestal, _stream()),
+            "lic_gdn_reparam")
+    return gamma_e
 
 
 class _GDNBF16Fn(torch.autograd.Function):
@@ -278,25 +299,26 @@ class _GDNBF16Fn(torch.autograd.Function):
         lib = L.load()
         xh = _as_bf16_nhwc(x)
         B, H, W, Cc = xh.shape
-        beta_c, gamma_c = beta.contiguous(), gamma.contiguous()
-        beta_e, gamma_e = torch.empty_like(beta_c), torch.empty_like(gamma_c)
-        L.check(lib.lic_gdn_reparam(_ptr(beta_c), _ptr(beta_e), Cc, beta_bound, pedestal, _stream()), "lic_gdn_reparam")
-        L.check(lib.lic_gdn_reparam(_ptr(gamma_c), _ptr(gamma_e), Cc * Cc, gamma_bound, pedestal, _stream()),
-                "lic_gdn_reparam")
-        gT = _pack_bf16(gamma_e, 1, Cc, Cc, 0, 1, Cc)
+        beta_e, gT = prepared(beta, "f32.beta_e"), prepared(gamma, "bf16.gdn_gT")
+        if beta_e is None or gT is None:
+            beta_c = beta.contiguous()
+            beta_e = torch.empty_like(beta_c)
+            L.check(lib.lic_gdn_reparam(_ptr(beta_c), _ptr(beta_e), Cc, beta_bound, pedestal, _stream()), "lic_gdn_reparam")
+            gT = _pack_bf16(_gamma_eff(gamma, gamma_bound, pedestal), 1, Cc, Cc, 0, 1, Cc)
         out, norm = torch.empty_like(xh), torch.empty_like(xh)
         P = B * H * W
         _igemm_bf16(xh, gT, out, B=1, Hi=1, Wi=P, Cin=Cc, Ho=1, Wo=P, Cout=Cc, kh=1, kw=1, stride=1, pad=0,
                     transposed=False, bias=beta_e, prologue=1, epilogue=L.EPI_IGDN if inverse else L.EPI_GDN,
                     out2=norm, aux=xh)
-        ctx.save_for_backward(xh, norm, gamma_e, beta_c, gamma_c)
-        ctx.cfg = (inverse, beta_bound, gamma_bound)
+        ctx.save_for_backward(xh, norm, beta, gamma)
+        ctx.cfg = (inverse, beta_bound, gamma_bound, pedestal)
         return _nchw_view(out)
 
     @staticmethod
     def backward(ctx, gy):
-        xh, norm, gamma_e, beta_c, gamma_c = ctx.saved_tensors
-        inverse, beta_bound, gamma_bound = ctx.cfg
+        xh, norm, beta, gamma = ctx.saved_tensors
+        inverse, beta_bound, gamma_bound, pedestal = ctx.cfg
+        beta_c, gamma_c = beta.contiguous(), gamma.contiguous()
         lib = L.load()
         g = _as_bf16_nhwc(gy)
         B, H, W, Cc = xh.shape
@@ -307,7 +329,10 @@ class _GDNBF16Fn(torch.autograd.Function):
         dx = dbeta = dgamma = None
         if ctx.needs_input_grad[0]:
             dxh = torch.empty_like(xh)
-            _igemm_bf16(t, _pack_bf16(gamma_e, 1, Cc, Cc, 0, Cc, 1), dxh, B=1, Hi=1, Wi=P, Cin=Cc, Ho=1, Wo=P, Cout=Cc,
+            gp = prepared(gamma, "bf16.gdn_g")
+            if gp is None:
+                gp = _pack_bf16(_gamma_eff(gamma, gamma_bound, pedestal), 1, Cc, Cc, 0, Cc, 1)
+            _igemm_bf16(t, gp, dxh, B=1, Hi=1, Wi=P, Cin=Cc, Ho=1, Wo=P, Cout=Cc,
                         kh=1, kw=1, stride=1, pad=0, transposed=False,
                         epilogue=L.EPI_IGDN_BWD if inverse else L.EPI_GDN_BWD, aux=g, aux2=xh, aux3=norm)
             dx = _nchw_view(dxh)
@@ -317,7 +342,7 @@ class _GDNBF16Fn(torch.autograd.Function):
             L.check(lib.lic_gdn_reparam_bwd(_ptr(beta_c), _ptr(dbe), _ptr(dbeta), Cc, beta_bound, _stream()),
                     "lic_gdn_reparam_bwd")
         if ctx.needs_input_grad[2]:
-            dge = torch.empty_like(gamma_e)
+            dge = torch.empty_like(gamma_c)
             _wgrad_bf16(t, xh, dge, B=1, Hs=1, Ws=P, Cp=Cc, Hl=1, Wl=P, Cg=Cc, kh=1, kw=1, stride=1, pad=0,
                         g_is_row=False, dst_sm=Cc, dst_sn=1, dst_stap=0, sq_g=1)
             dgamma = torch.empty_like(gamma_c)

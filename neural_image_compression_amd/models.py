@@ -58,6 +58,8 @@ class _HyperpriorContextModel(nn.Module):
         the likelihood / coder-table kernels read).  `_fork(y_in)` is called as soon as y_in exists."""
         if x.shape[2] % 64 or x.shape[3] % 64:
             raise RuntimeError("H and W must be multiples of 64 (phi/psi shapes must agree, Models.py:73)")
+        if self.use_step_prep and x.is_cuda:
+            self.step_prep().run()   # one launch: every packed weight / GDN re-parametrisation of this step
         y = self.encoder(x)
         if training:
             if noise is None:
@@ -99,6 +101,15 @@ class _HyperpriorContextModel(nn.Module):
     # stream beside the latent-side branch (many small launches that cannot fill 256 CUs by
     # themselves), in forward and -- autograd replays each op on its forward stream -- in backward.
     overlap_branches = True
+    # all parameter-derived buffers refreshed by one launch per optimizer step (prep.StepPrep); LIC_STEP_PREP=0
+    # restores the per-layer packing launches for an A/B
+    use_step_prep = os.environ.get("LIC_STEP_PREP", "1") != "0"
+
+    def step_prep(self):
+        if getattr(self, "_step_prep", None) is None:
+            from .prep import StepPrep
+            self._step_prep = StepPrep(self)
+        return self._step_prep
 
     def side_stream(self):
         """the second HIP stream of `overlap_branches` (created on first use)"""

@@ -3,18 +3,25 @@ sharded, and ONE exchange step -- an all-reduce(mean) of the gradients over RCCL
 optimizer.step().  The reference has no distributed code at all: the contract
 is "same gradients as one big batch" (rd_loss terms are batch means, RateDistortionLoss.py:20-27).
 
-Gradients are reduced in a few large flat buckets (sized for xGMI's per-link bandwidth, not for
-NVSwitch): a bucket's all-reduce is launched from an autograd hook as soon as its last gradient
-has been accumulated, so it overlaps the rest of backward; `finish()` waits and writes the
-averaged values back.  Works with any torch.distributed backend ("nccl" = RCCL on ROCm; "gloo"
-in the CPU tests).
+Gradients live in a few large flat buckets that are allocated ONCE (sized for xGMI's per-link
+bandwidth, not for NVSwitch).  Every parameter's gradient is a view into its bucket, and the weight-
+gradient kernels write there directly (`functional.grad_like` hands the view to lic_wgrad as its
+destination: 99 % of the gradient bytes never move again); a gradient that autograd produced elsewhere
+(small vectors, split views) is copied into its slot when it arrives.  A bucket's all-reduce is launched
+from an autograd hook as soon as its last gradient exists, so it overlaps the rest of backward;
+`finish()` waits (and, for back-ends without an averaging collective, scales each bucket with one
+multiply).  No per-step concatenation, no per-step allocation.  Works with any torch.distributed
+back-end ("nccl" = RCCL on ROCm; "gloo" in the CPU tests).
 """
 from __future__ import annotations
 
-from typing import List, Optional
+import weakref
+from typing import List
 
 import torch
 import torch.distributed as dist
+
+from . import functional as F_
 
 
 class GradientAllReducer:
@@ -26,8 +33,8 @@ class GradientAllReducer:
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.force = bool(force) and dist.is_initialized()
-        # RCCL can average in the collective; the gradients then become views of the bucket buffer and
-        # finish() launches nothing (gloo has no AVG: sum, then one multiply per parameter)
+        self.active = self.world > 1 or self.force
+        # RCCL can average in the collective (gloo has no AVG: sum, then one multiply per bucket)
         self._avg = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         self.overlap = overlap
         # buckets in reverse registration order ~ the order backward produces gradients.  `stream_groups`
@@ -58,7 +65,23 @@ class GradientAllReducer:
         for b, idxs in enumerate(self.buckets):
             for i in idxs:
                 self._bucket_of[i] = b
-        self._flat: List[Optional[torch.Tensor]] = [None] * len(self.buckets)
+        # persistent flat buffers + one gradient view per parameter (16-byte aligned slots: the weight-
+        # gradient kernels and the optimizer's vectorised loads want that)
+        self._flat: List[torch.Tensor] = []
+        self._views: List[torch.Tensor] = [None] * len(self.params)
+        if self.active:
+            for idxs in self.buckets:
+                p0 = self.params[idxs[0]]
+                offs, off = [], 0
+                for i in idxs:
+                    offs.append(off)
+                    off += (self.params[i].numel() + 3) // 4 * 4
+                flat = torch.zeros(off, device=p0.device, dtype=p0.dtype)
+                self._flat.append(flat)
+                for i, o in zip(idxs, offs):
+                    p = self.params[i]
+                    self._views[i] = flat[o:o + p.numel()].view(p.shape)
+                    F_.GRAD_VIEWS[id(p)] = (weakref.ref(p), self._views[i])
         self._pending = [0] * len(self.buckets)
         self._work = [None] * len(self.buckets)
         self._events = [[] for _ in self.buckets]  # one per gradient: backward may run on several streams
@@ -66,7 +89,7 @@ class GradientAllReducer:
         # the closing hook, so stream order already covers it; otherwise fence each gradient with an event
         self._fence = not (stream_groups and group_streams)
         self._hooks = []
-        if (self.world > 1 or self.force) and overlap:
+        if self.active and overlap:
             # Registering a hook creates (and pins) the parameter's AccumulateGrad node on the CURRENT
             # stream.  A group whose gradients are produced on another stream registers under that stream
             # (`group_streams`), else autograd would synchronise the two streams at every such gradient.
@@ -85,6 +108,10 @@ class GradientAllReducer:
         self.reset()
 
     def reset(self):
+        # indices of the parameters whose gradient had to be copied into its slot during the step that just
+        # ended (diagnostic: the weight-gradient kernels are expected to write theirs in place)
+        self.copied_last_step = getattr(self, "_copied", [])
+        self._copied = []
         for b, idxs in enumerate(self.buckets):
             self._pending[b] = len(idxs)
             self._work[b] = None
@@ -93,6 +120,7 @@ class GradientAllReducer:
     def _make_hook(self, i):
         def hook(_p):
             b = self._bucket_of[i]
+            self._adopt(i)
             if self._fence and _p.grad is not None and _p.grad.is_cuda:
                 # the model overlaps its decoder and latent branches on two HIP streams, so a bucket's
                 # gradients can come from different streams: fence each one where it was produced
@@ -104,48 +132,55 @@ class GradientAllReducer:
                 self._launch(b)
         return hook
 
+    def _adopt(self, i):
+        """make parameter i's gradient the view into its bucket (a no-op when the kernel wrote it there)"""
+        p, v = self.params[i], self._views[i]
+        g = p.grad
+        if g is None:
+            v.zero_()
+        elif g.data_ptr() != v.data_ptr() or g.stride() != v.stride():
+            v.copy_(g)
+            self._copied.append(i)
+        p.grad = v
+
     def _launch(self, b):
-        ps = [self.params[i] for i in self.buckets[b]]
         for ev in self._events[b]:
             torch.cuda.current_stream().wait_event(ev)
-        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in ps]
-        flat = torch.cat([g.reshape(-1) for g in grads])
-        self._flat[b] = flat
-        self._work[b] = dist.all_reduce(flat, op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM,
+        self._work[b] = dist.all_reduce(self._flat[b], op=dist.ReduceOp.AVG if self._avg else dist.ReduceOp.SUM,
                                         group=self.group, async_op=True)
 
     def finish(self):
         """Call after backward(), before optimizer.step()."""
-        if self.world == 1 and not self.force:
+        if not self.active:
             return
-        for b in range(len(self.buckets)):
-            if self._work[b] is None:
-                self._launch(b)
-        inv = 1.0 / self.world
         for b, idxs in enumerate(self.buckets):
+            if self._work[b] is None:   # no hooks (overlap off) or a parameter that received no gradient
+                for i in idxs:
+                    self._adopt(i)
+                self._launch(b)
+        for b in range(len(self.buckets)):
             self._work[b].wait()
-            flat = self._flat[b]
-            if flat.is_cuda:  # allocated on whichever stream ran the hook; read here on the current one
-                flat.record_stream(torch.cuda.current_stream())
-            off = 0
-            for i in idxs:
-                p = self.params[i]
-                n = p.numel()
-                g = flat[off:off + n].view_as(p)
-                if self._avg:
-                    p.grad = g
-                elif p.grad is None:
-                    p.grad = (g * inv).clone()
-                else:
-                    torch.mul(g, inv, out=p.grad)
-                off += n
-            self._flat[b] = None
+            if not self._avg and self.world > 1:
+                self._flat[b].mul_(1.0 / self.world)
         self.reset()
 
     def remove(self):
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        for p in self.params:
+            F_.GRAD_VIEWS.pop(id(p), None)
+
+
+def all_reduce_mean_scalars(values, device=None, process_group=None):
+    """Mean over ranks of a few Python floats (validation losses, logging scalars): one tiny collective."""
+    if not dist.is_initialized() or dist.get_world_size(process_group) == 1:
+        return [float(v) for v in values]
+    dev = device if (device is not None and dist.get_backend(process_group) == "nccl") else "cpu"
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=process_group)
+    t /= dist.get_world_size(process_group)
+    return [float(v) for v in t.tolist()]
 
 
 def broadcast_parameters(module: torch.nn.Module, src: int = 0, process_group=None):

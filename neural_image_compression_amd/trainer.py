@@ -24,7 +24,7 @@ import torch
 import torch.distributed as dist
 from torch.optim.lr_scheduler import CosineAnnealingLR, ReduceLROnPlateau
 
-from .parallel import GradientAllReducer, broadcast_parameters
+from .parallel import GradientAllReducer, all_reduce_mean_scalars, broadcast_parameters
 
 
 class _JsonlWriter:
@@ -238,6 +238,10 @@ class Trainer:
         self.model.train()
         n = len(self.val_loader)
         avg_loss, avg_bpp, avg_psnr = total_loss / n, bpp_loss / n, psnr_loss / n
+        if self.distributed:
+            # every rank validates its own shard of the images: average the three numbers over the ranks, so that
+            # ReduceLROnPlateau sees the SAME value everywhere and the replicated parameters cannot drift apart
+            avg_loss, avg_bpp, avg_psnr = all_reduce_mean_scalars((avg_loss, avg_bpp, avg_psnr), self.device)
         if self.writer is not None:
             self.writer.add_scalar("validation/validation_loss", avg_loss, self.step)
             self.writer.add_scalar("validation/validation_bpp", avg_bpp, self.step)

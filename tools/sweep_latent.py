@@ -37,6 +37,14 @@ LAYERS = [
 ]
 
 
+# the RGB-side dense GEMMs (column buffers [pixels][80]) at 128x128: rows = B*128*128 pixels, 1x1 "layers"
+P128 = 128 * 128
+IMAGE_GEMMS = [
+    ("stem/head-dx K80 N192", 80, 192),
+    ("head fwd K192 N80", 192, 80),
+]
+
+
 def time_launch(fn):
     fn()
     torch.cuda.synchronize()
@@ -88,5 +96,34 @@ def main():
             print(f"{tag:20s} auto {auto * 1e3:6.0f}us {flops / auto / 1e9:5.0f}TF | {best}", flush=True)
 
 
+def image_gemms():
+    only = sys.argv[1:] or None
+    for name, Kd, Nd in IMAGE_GEMMS:
+        if only and not any(o in name for o in only):
+            continue
+        P = B * P128
+        x = torch.randn(P, Kd, device=dev)
+        w = torch.randn(Kd, Nd, device=dev) * 0.05
+        wp = F_._pack_dense(w)
+        out = torch.empty(P, Nd, device=dev)
+        g = dict(B=1, Hi=1, Wi=P, Cin=Kd, Ho=1, Wo=P, Cout=Nd, kh=1, kw=1, stride=1, pad=0, transposed=False)
+        flops = 2.0 * P * Kd * Nd
+        byts = 4.0 * P * (Kd + Nd)
+        res = []
+        for c in [None] + [(bm, tn, 0) for bm in (64, 128) for tn in (1, 2, 3)]:
+            F_.FORCE_IGEMM = c
+            try:
+                ms = time_launch(lambda: F_._igemm(x, wp, out, **g))
+            except L.LicError:
+                continue
+            finally:
+                F_.FORCE_IGEMM = None
+            res.append((ms, c))
+        res.sort(key=lambda r: r[0])
+        print(f"{name:24s} " + ", ".join(f"{c}: {ms * 1e3:.0f}us {flops / ms / 1e9:.0f}TF {byts / ms / 1e9:.2f}TB/s"
+                                          for ms, c in res), flush=True)
+
+
 if __name__ == "__main__":
+    image_gemms()
     main()
