@@ -235,7 +235,7 @@ def grad_like(param: torch.Tensor) -> torch.Tensor:
     copy), else a fresh contiguous tensor."""
     e = GRAD_VIEWS.get(id(param)) if GRAD_VIEWS else None
     if e is not None and e[0]() is param and param.grad is None:
-        return e[1]
+        return e[1].detach()   # a fresh handle on the slot: autograd adopts a gradient only if nobody else holds it
     return torch.empty_like(param, memory_format=torch.contiguous_format)
 
 

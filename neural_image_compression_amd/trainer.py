@@ -50,39 +50,41 @@ def _make_writer(log_dir, purge_step):
         return _JsonlWriter(log_dir, purge_step)
 
 
+def _interval(explicit, max_steps, fraction):
+    """the reference's default cadence: max_steps / fraction steps (Trainer.py:27-29)"""
+    return explicit if explicit else int(max_steps / fraction)
+
+
+def _build_scheduler(kind, optimizer, max_steps):
+    """'plateau' -> ReduceLROnPlateau(min, patience 100, factor 0.5); 'cosine' -> CosineAnnealingLR(T_max =
+    max_steps, eta_min 1e-5); anything else -> none (Trainer.py:32-40).  Returns (scheduler, steps_on_val_loss)."""
+    if kind == "plateau":
+        return ReduceLROnPlateau(optimizer, mode="min", patience=100, factor=0.5), True
+    if kind == "cosine":
+        return CosineAnnealingLR(optimizer, T_max=max_steps, eta_min=1e-5), False
+    return None, False
+
+
 class Trainer:
     def __init__(self, model, optimizer, train_loader, val_loader=None, rd_loss=None, lambda_val=0.005,
                  scheduler=None, max_steps=10000, resume=False, log_interval=None, img_interval=None,
                  val_interval=None, log_dir="runs/experiment", checkpoint_path="./checkpoints/checkpoint.pth",
                  device="cuda", distributed: Optional[bool] = None, writer=None):
-        self.model = model.to(device)
-        self.optimizer = optimizer
-        self.train_loader = train_loader
-        self.val_loader = val_loader
         if rd_loss is None:
             raise ValueError("You must provide a rate-distortion loss function (`rd_loss`)")
-        self.rd_loss = rd_loss
-        self.lambda_val = lambda_val
         self.device = device
-        self.max_steps = max_steps
-        self.step = 0
+        self.model = model.to(device)
+        self.optimizer, self.rd_loss, self.lambda_val = optimizer, rd_loss, lambda_val
+        self.train_loader, self.val_loader = train_loader, val_loader
         self.train_iter = iter(train_loader)
-        self.log_interval = log_interval if log_interval else int(self.max_steps / 200)
+        self.step, self.max_steps = 0, max_steps
+        self.log_interval = _interval(log_interval, max_steps, 200)
+        self.img_interval = _interval(img_interval, max_steps, 25)
+        self.val_interval = _interval(val_interval, max_steps, 200)
         self.log_statistics = True  # latent / likelihood summaries every log_interval (Trainer.py:88-92)
-        self.img_interval = img_interval if img_interval else int(self.max_steps / 25)
-        self.val_interval = val_interval if val_interval else int(self.max_steps / 200)
-        if scheduler == 'plateau':
-            self.scheduler = ReduceLROnPlateau(optimizer, mode='min', patience=100, factor=0.5)
-            self.use_plateau = True
-        elif scheduler == 'cosine':
-            self.scheduler = CosineAnnealingLR(optimizer, T_max=max_steps, eta_min=1e-5)
-            self.use_plateau = False
-        else:
-            self.scheduler = None
-            self.use_plateau = False
-        self.resume = resume
-        self.checkpoint_path = checkpoint_path
-        if self.resume and self.checkpoint_path is not None and os.path.exists(self.checkpoint_path):
+        self.scheduler, self.use_plateau = _build_scheduler(scheduler, optimizer, max_steps)
+        self.resume, self.checkpoint_path = resume, checkpoint_path
+        if resume and checkpoint_path is not None and os.path.exists(checkpoint_path):
             self.load_checkpoint()
         # data parallel: one process per GPU; gradients all-reduced (mean) once per step
         self.distributed = dist.is_initialized() if distributed is None else distributed
@@ -100,31 +102,30 @@ class Trainer:
                 group_streams=[self.model.side_stream()] if two else None)
         self.writer = writer if writer is not None else (_make_writer(log_dir, self.step) if self.rank == 0 else None)
 
-    # -- checkpointing (Trainer.py:52-71) --------------------------------------------------------
+    # -- checkpointing: the reference's file format (Trainer.py:52-71) ---------------------------
+    def _checkpoint_state(self):
+        sched = None if self.scheduler is None else self.scheduler.state_dict()
+        return {"model": self.model.state_dict(), "optimizer": self.optimizer.state_dict(), "step": self.step,
+                "scheduler": sched}
+
     def save_checkpoint(self):
-        if self.rank != 0:
+        if self.rank != 0:   # replicas are identical: one writer
             return
-        checkpoint = {
-            "model": self.model.state_dict(),
-            "optimizer": self.optimizer.state_dict(),
-            "step": self.step,
-            "scheduler": self.scheduler.state_dict() if self.scheduler is not None else None,
-        }
-        d = os.path.dirname(self.checkpoint_path)
-        if d:
-            os.makedirs(d, exist_ok=True)
-        torch.save(checkpoint, self.checkpoint_path)
-        print(f"Checkpoint saved at step {self.step} -> {self.checkpoint_path}")
+        folder = os.path.dirname(self.checkpoint_path)
+        if folder:
+            os.makedirs(folder, exist_ok=True)
+        torch.save(self._checkpoint_state(), self.checkpoint_path)
+        print(f"[trainer] step {self.step}: checkpoint written to {self.checkpoint_path}")
 
     def load_checkpoint(self):
-        checkpoint = torch.load(self.checkpoint_path, map_location=self.device)
-        self.model.load_state_dict(checkpoint["model"])
-        self.optimizer.load_state_dict(checkpoint["optimizer"])
-        if self.scheduler is not None and checkpoint["scheduler"] is not None:
-            self.scheduler.load_state_dict(checkpoint["scheduler"])
-        self.step = checkpoint["step"]
-        self.max_steps += self.step
-        print(f"Checkpoint loaded -> Resuming from step {self.step}")
+        state = torch.load(self.checkpoint_path, map_location=self.device)
+        self.model.load_state_dict(state["model"])
+        self.optimizer.load_state_dict(state["optimizer"])
+        if self.scheduler is not None and state["scheduler"] is not None:
+            self.scheduler.load_state_dict(state["scheduler"])
+        self.step = state["step"]
+        self.max_steps += self.step   # `max_steps` counts the steps of THIS run (Trainer.py:70)
+        print(f"[trainer] resumed from {self.checkpoint_path} at step {self.step}")
 
     # -- the step (Trainer.py:78-86) -------------------------------------------------------------
     def train_step(self, imgs):
@@ -164,18 +165,20 @@ class Trainer:
             self.save_checkpoint()
 
     def _next_batch(self):
-        try:
-            return next(self.train_iter)
-        except StopIteration:
+        """next training batch; the loader is restarted when it runs out (Trainer.py:133-138)"""
+        batch = next(self.train_iter, None)
+        if batch is None:
             self.train_iter = iter(self.train_loader)
-            return next(self.train_iter)
+            batch = next(self.train_iter)
+        return batch
 
     def _log_scalars(self, results):
+        """every plain number of the loss dict under losses/<key> (Trainer.py:140-143)"""
         if self.writer is None:
             return
-        for k, v in results.items():
-            if isinstance(v, (float, int)):
-                self.writer.add_scalar(f"losses/{k}", v, self.step)
+        for key, value in results.items():
+            if isinstance(value, (float, int)):
+                self.writer.add_scalar("losses/" + key, value, self.step)
 
     # ---- Trainer.py:167-217 from device-side summaries --------------------------------------
     @staticmethod
@@ -225,25 +228,24 @@ class Trainer:
             self.writer.add_scalar("entropy_params/used_components_mean", float(used), self.step)
 
     def _validate(self):
+        """mean loss / bpp / PSNR over the validation loader in eval mode (Trainer.py:145-165); under data
+        parallelism the three means are averaged over the ranks"""
+        sums = [0.0, 0.0, 0.0]
         self.model.eval()
-        total_loss = bpp_loss = psnr_loss = 0.0
         with torch.no_grad():
             for imgs in self.val_loader:
                 imgs = imgs.to(self.device)
-                model_out = self.model(imgs, training=False)
-                results = self.rd_loss(model_out, imgs, self.lambda_val)
-                total_loss += float(results['loss'])
-                bpp_loss += results['bpp_total']
-                psnr_loss += results['psnr']
+                res = self.rd_loss(self.model(imgs, training=False), imgs, self.lambda_val)
+                for i, v in enumerate((res["loss"], res["bpp_total"], res["psnr"])):
+                    sums[i] += float(v)
         self.model.train()
-        n = len(self.val_loader)
-        avg_loss, avg_bpp, avg_psnr = total_loss / n, bpp_loss / n, psnr_loss / n
+        means = [v / len(self.val_loader) for v in sums]
         if self.distributed:
             # every rank validates its own shard of the images: average the three numbers over the ranks, so that
             # ReduceLROnPlateau sees the SAME value everywhere and the replicated parameters cannot drift apart
-            avg_loss, avg_bpp, avg_psnr = all_reduce_mean_scalars((avg_loss, avg_bpp, avg_psnr), self.device)
+            means = all_reduce_mean_scalars(means, self.device)
         if self.writer is not None:
-            self.writer.add_scalar("validation/validation_loss", avg_loss, self.step)
-            self.writer.add_scalar("validation/validation_bpp", avg_bpp, self.step)
-            self.writer.add_scalar("validation/validation_pnsr", avg_psnr, self.step)
-        return avg_loss
+            # (tag spelling as in the reference, Trainer.py:162-164)
+            for tag, v in zip(("validation_loss", "validation_bpp", "validation_pnsr"), means):
+                self.writer.add_scalar("validation/" + tag, v, self.step)
+        return means[0]

@@ -156,3 +156,53 @@ def test_trainer_step_loop_and_checkpoint(tmp_path):
     assert t2.step == 7 and t2.max_steps == 12                        # max_steps += step (Trainer.py:70)
     assert Trainer(_FakeModel(), opt, data, rd_loss=_fake_loss, max_steps=10000, device="cpu",
                    writer=_Rec()).log_interval == 50                  # max_steps/200 (Trainer.py:27)
+
+
+@pytest.mark.parametrize("name,cls", [("model_jah_M8_K3.npz", nic.JointAutoregressiveHierarchical),
+                                      ("model_hmr_M8_K3.npz", nic.HierarchicalMixtureResidual)])
+def test_reference_format_checkpoint_file_round_trip(golden_dir, tmp_path, name, cls):
+    """a `.pth` in the reference's checkpoint format (Trainer.py:52-61: dict with `model`,
+    `optimizer`, `step`, `scheduler`; the model's state dict under the REFERENCE's key names in the reference's
+    order, incl. the CompressAI GDN parametrizer buffers -- the key list was captured from the reference's own
+    Models.py into tests/golden) goes through `Trainer(resume=True)` (Trainer.py:63-71) into this package's model:
+    every tensor arrives, Adam's moments land on the right parameters, step / max_steps / scheduler resume,
+    and a checkpoint written back has the same keys."""
+    import golden_recipe as R
+    from torch.optim.lr_scheduler import CosineAnnealingLR
+    fx = np.load(os.path.join(golden_dir, name))
+    ks = [(k, tuple(s)) for k, s in json.loads(str(fx["keys_shapes"]))]
+    M, K = int(fx["M"]), int(fx["K"])
+    ref_sd = {k: torch.from_numpy(v) for k, v in R.make_state(ks, 5).items()}
+    # the writer side, with no code of this package: parameters in the reference's registration order
+    buffers = ("pedestal", "bound", "mask")
+    plist = [torch.nn.Parameter(v.clone()) for k, v in ref_sd.items() if k.split(".")[-1] not in buffers]
+    wopt = torch.optim.Adam(plist, lr=3e-4)
+    wsched = CosineAnnealingLR(wopt, T_max=50, eta_min=1e-5)
+    for i, p in enumerate(plist):
+        p.grad = torch.full_like(p, 0.01 * (i + 1))
+    wopt.step()
+    wsched.step()
+    path = str(tmp_path / "reference_format.pth")
+    torch.save({"model": dict(ref_sd), "optimizer": wopt.state_dict(), "step": 37, "scheduler": wsched.state_dict()}, path)
+
+    model = cls(M, K)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    tr = Trainer(model, opt, [torch.zeros(1, 3, 64, 64)], rd_loss=_fake_loss, scheduler="cosine", max_steps=50,
+                 resume=True, checkpoint_path=path, device="cpu", writer=_Rec())
+    assert tr.step == 37 and tr.max_steps == 87
+    sd = model.state_dict()
+    assert list(sd.keys()) == [k for k, _ in ks]
+    for k, v in ref_sd.items():
+        assert torch.equal(sd[k], v), k
+    named = [n for n, _ in model.named_parameters()]
+    assert named == [k for k, _ in ks if k.split(".")[-1] not in buffers]      # same parameter order as the writer
+    for i, p in enumerate(model.parameters()):
+        st = opt.state[p]
+        assert torch.equal(st["exp_avg"], wopt.state[plist[i]]["exp_avg"]) and float(st["step"]) == 1.0
+    assert opt.param_groups[0]["lr"] == wopt.param_groups[0]["lr"] and tr.scheduler.last_epoch == 1
+    out = str(tmp_path / "written_back.pth")
+    tr.checkpoint_path = out
+    tr.save_checkpoint()
+    back = torch.load(out)
+    assert set(back) == {"model", "optimizer", "step", "scheduler"} and list(back["model"].keys()) == [k for k, _ in ks]
+    assert all(torch.equal(back["model"][k], v) for k, v in ref_sd.items())
