@@ -254,6 +254,9 @@ def main():
                 a[1] += e0.elapsed_time(e1) * 1e-3
                 a[2] += flops
                 a[3] += abytes
+            # (the event objects are released before anything else is timed: with ~800 of them alive, ROCm 7.0
+            # slowed every later launch of this process down -- the analysis forward below read 20 ms instead of 4)
+            del prof[:]
             dom = max(agg, key=lambda k: agg[k][1])
             n, secs, flops, abytes = agg[dom]
             ach = flops / secs / 1e12

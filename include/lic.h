@@ -256,8 +256,8 @@ int lic_rd_loss_bwd(const float* x_hat, const float* x, int64_t ny, int64_t nz, 
 /* ---- bf16-storage variants (BASELINE config 3) --------------------------------------------------
  * Activations / auxiliaries are bf16 NHWC (pitches and channel counts multiples of 8), weights are
  * packed to bf16 by lic_pack_weight_bf16 ([tap][ceil(K/32)][ceil64(N)/32][2][64 lanes][8], MFMA operand order), bias and all
- * accumulation are fp32 (v_mfma_f32_32x32x16_bf16).  lic_igemm_bf16 supports the NONE / GDN / IGDN
- * / GDN_BWD / IGDN_BWD epilogues (no residual); `out` is bf16, or fp32 when out_f32 != 0.
+ * accumulation are fp32 (v_mfma_f32_32x32x16_bf16).  lic_igemm_bf16 supports the NONE / LEAKY / GDN /
+ * IGDN / GDN_BWD / IGDN_BWD epilogues (no residual) and tap_mask; `out` is bf16, or fp32 when out_f32 != 0.
  * Parameter gradients (lic_wgrad_bf16 dst, lic_colsum_bf16 out) are fp32. */
 int64_t lic_packed_weight_bf16_elems(int32_t taps, int32_t K, int32_t N);
 int lic_pack_weight_bf16(const float* src, void* dst, int32_t taps, int32_t K, int32_t N, int64_t s_tap,
@@ -279,6 +279,8 @@ int lic_col2im_bf16(const void* col, const float* bias, float* out, int32_t B, i
 size_t lic_colsum_bf16_workspace_bytes(int64_t P, int32_t C);
 int lic_colsum_bf16(const void* in, int64_t ld, int64_t P, int32_t C, float scale, float* out,
                     void* workspace, size_t workspace_bytes, lic_stream_t stream);
+/* dx = dy * (y > 0 ? 1 : slope), bf16 tensors, n % 8 == 0: backward of lic_igemm_bf16's LIC_EPI_LEAKY */
+int lic_leaky_bwd_bf16(const void* y, const void* dy, void* dx, int64_t n, float slope, lic_stream_t stream);
 int lic_gdn_dnorm_bf16(const void* g, const void* x, const void* norm, void* t, int64_t n, int32_t inverse,
                        lic_stream_t stream);
 

@@ -11,11 +11,12 @@ from .layers import (Conv2d, ConvTranspose2d, GDN, LeakyReLU, ResidualBlock, Res
 
 
 class _Stack(nn.Module):
-    precision = "fp32"  # "bf16": bf16 activations between the layers (5x5 conv/GDN stacks only)
+    precision = "fp32"  # "bf16": bf16 activations between the layers (5x5 stacks and the hyper stacks)
+    out_f32 = True      # bf16 mode: the stack's result in fp32 (latents, image) or bf16 (features for a bf16 consumer)
 
     def forward(self, x):
         if self.precision == "bf16":
-            return run_bf16(self.net, x)
+            return run_bf16(self.net, x, self.out_f32)
         return run_fused(self.net, x)
 
 

@@ -183,3 +183,25 @@ LIC_EXPORT int lic_gdn_dnorm_bf16(const void* g, const void* x, const void* norm
                      (const bf16_t*)g, (const bf16_t*)x, (const bf16_t*)norm, (bf16_t*)t, (long)(n / 8), inverse);
   return lic_check_launch();
 }
+
+// dx = dy * (y > 0 ? 1 : slope) on bf16 tensors (y = the LeakyReLU OUTPUT: its sign is the input's);
+// 8 elements per lane.  Backward of the fused LIC_EPI_LEAKY epilogue of lic_igemm_bf16.
+__global__ __launch_bounds__(256) void leaky_bwd_bf16_kernel(const bf16_t* y, const bf16_t* dy, bf16_t* dx, long n8,
+                                                             float slope) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+    const bf16x8 a = reinterpret_cast<const bf16x8*>(y)[i], g = reinterpret_cast<const bf16x8*>(dy)[i];
+    bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (float)a[e] > 0.0f ? g[e] : (bf16_t)((float)g[e] * slope);
+    reinterpret_cast<bf16x8*>(dx)[i] = o;
+  }
+}
+LIC_EXPORT int lic_leaky_bwd_bf16(const void* y, const void* dy, void* dx, int64_t n, float slope, lic_stream_t stream) {
+  if (!y || !dy || !dx || n < 0) return LIC_ERR_INVALID;
+  if (n % 8 || ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15))
+    return LIC_ERR_UNSUPPORTED;
+  if (n == 0) return LIC_OK;
+  hipLaunchKernelGGL(leaky_bwd_bf16_kernel, dim3(ew_grid(n / 8, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)y, (const bf16_t*)dy, (bf16_t*)dx, (long)(n / 8), slope);
+  return lic_check_launch();
+}

@@ -45,6 +45,7 @@ struct IgemmHParams {
   long in_ld, out_ld, out2_ld, aux_ld, aux2_ld, aux3_ld;
   int B, Hi, Wi, Cin, Ho, Wo, Cout;
   int kw, stride, pad, transposed, prologue, epilogue, out_f32;
+  float slope;  // LIC_EPI_LEAKY
   int cpt, Npad, nphase, MT, NT;
   int pgroup, porder;  // 4-phase launches: phase-sorted groups of `pgroup` M tiles, order 2 bits per rank
   int ntaps[4];
@@ -310,7 +311,10 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
             v[4 + e] = v1[e] + bias8[4 + e];
           }
         }
-        if (epi == LIC_EPI_GDN || epi == LIC_EPI_IGDN) {
+        if (epi == LIC_EPI_LEAKY) {  // hyper / entropy-parameter layers (Components.py:70-72,100-102; ParametersModels.py:23-25)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = v[e] > 0.0f ? v[e] : v[e] * p.slope;
+        } else if (epi == LIC_EPI_GDN || epi == LIC_EPI_IGDN) {
           if (p.out2) {
             bf16x8 nb;
 #pragma unroll
@@ -398,8 +402,8 @@ static int igemmh_prepare(const lic_igemm_desc* d, int32_t out_f32, IgemmHParams
     return LIC_ERR_INVALID;
   if (d->kh * d->kw > 28 || d->stride < 1 || d->stride > 2) return LIC_ERR_UNSUPPORTED;
   const int epi = d->epilogue;
-  if (!(epi == LIC_EPI_NONE || epi == LIC_EPI_GDN || epi == LIC_EPI_IGDN || epi == LIC_EPI_GDN_BWD ||
-        epi == LIC_EPI_IGDN_BWD) || d->res)
+  if (!(epi == LIC_EPI_NONE || epi == LIC_EPI_LEAKY || epi == LIC_EPI_GDN || epi == LIC_EPI_IGDN ||
+        epi == LIC_EPI_GDN_BWD || epi == LIC_EPI_IGDN_BWD) || d->res)
     return LIC_ERR_UNSUPPORTED;
   if ((epi == LIC_EPI_GDN || epi == LIC_EPI_IGDN) && !d->aux) return LIC_ERR_INVALID;
   if ((epi == LIC_EPI_GDN_BWD || epi == LIC_EPI_IGDN_BWD) && (!d->aux || !d->aux2 || !d->aux3)) return LIC_ERR_INVALID;
@@ -438,6 +442,7 @@ static int igemmh_prepare(const lic_igemm_desc* d, int32_t out_f32, IgemmHParams
   p.prologue = d->prologue;
   p.epilogue = epi;
   p.out_f32 = out_f32 ? 1 : 0;
+  p.slope = d->slope;
   p.cpt = (d->Cin + HB_BK - 1) / HB_BK;
   p.Npad = ((d->Cout + 63) / 64) * 64;  // whole 64-column wave pairs: every tile is full
   const uint32_t mask = d->tap_mask ? d->tap_mask : 0xFFFFFFFFu;

@@ -11,7 +11,8 @@ import torch.nn as nn
 from torch import Tensor
 
 from . import functional as F_
-from .layers import Conv2d, LeakyReLU, run_fused
+from . import functional_bf16 as FB_
+from .layers import Conv2d, LeakyReLU, run_bf16, run_fused
 
 
 class EntropyModel(nn.Module):
@@ -154,25 +155,30 @@ class MaskedConv2d(Conv2d):
                     live |= 1 << (r * kW + s)
         self._tap_mask = live
 
-    def forward(self, x: Tensor) -> Tensor:
+    def forward(self, x: Tensor, bf16: bool = False) -> Tensor:
         if F_.prepared(self.weight, "masked") is None:  # else this step's lic_prep_run already masked it in place
             F_.mask_weight_(self.weight, self.mask)
         s, p = self.stride[0], self.padding[0]
+        if bf16:  # bf16 features out (they feed the bf16 entropy-parameter MLP)
+            return FB_.conv2d_bf16(x, self.weight, self.bias, s, p, False, False, 0.01, self._tap_mask)
         return F_.conv2d(x, self.weight, self.bias, s, p, False, 0.01, self._tap_mask)
 
 
 class ContextModel(nn.Module):
+    precision = "fp32"  # "bf16": bf16 operands / features (models.set_precision)
+
     def __init__(self, latent_channels=192):
         super().__init__()
         self.masked = MaskedConv2d("A", in_channels=latent_channels, out_channels=2 * latent_channels,
                                    kernel_size=5, stride=1, padding=2)
 
     def forward(self, x):
-        return self.masked(x)
+        return self.masked(x, bf16=self.precision == "bf16")
 
 
 class EntropyParameters(nn.Module):
     """1x1-conv MLP 4M -> 640 -> 640 -> {2M | 3KM} (ParametersModels.py:8-64)."""
+    precision = "fp32"
 
     def __init__(self, latent_channels=192, hyper_latent_channels=192, K=1):
         super().__init__()
@@ -190,7 +196,10 @@ class EntropyParameters(nn.Module):
 
     def packed(self, combined_feat: Tensor) -> Tensor:
         """Activated parameters as ONE tensor [B, G*K*M, h, w] (what the likelihood kernel reads)."""
-        raw = run_fused(self.net, combined_feat)
+        if self.precision == "bf16":  # bf16 hidden features, fp32 raw parameters out of the last layer
+            raw = run_bf16(self.net, combined_feat, out_f32=True)
+        else:
+            raw = run_fused(self.net, combined_feat)
         return F_.entropy_params_activation(raw, self.latent_channels, self.K)
 
     def split(self, act: Tensor):

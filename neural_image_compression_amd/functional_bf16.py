@@ -56,7 +56,7 @@ def _pack_conv_weight_bf16(w, transposed_weight, for_dgrad):
 
 
 def _igemm_bf16(inp, w_packed, out, *, B, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, pad, transposed, bias=None,
-                prologue=0, epilogue=L.EPI_NONE, out2=None, aux=None, aux2=None, aux3=None):
+                prologue=0, epilogue=L.EPI_NONE, out2=None, aux=None, aux2=None, aux3=None, slope=0.01, tap_mask=0):
     d = L.IgemmDesc()
     d.in_, d.w, d.bias, d.out, d.out2 = _ptr(inp), _ptr(w_packed), _ptr(bias), _ptr(out), _ptr(out2)
     d.aux, d.aux2, d.aux3, d.res = _ptr(aux), _ptr(aux2), _ptr(aux3), None
@@ -65,7 +65,7 @@ def _igemm_bf16(inp, w_packed, out, *, B, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, str
     d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout = B, Hi, Wi, Cin, Ho, Wo, Cout
     d.kh, d.kw, d.stride, d.pad = kh, kw, stride, pad
     d.transposed, d.prologue, d.epilogue = int(transposed), prologue, epilogue
-    d.tap_mask, d.slope = 0, 0.01
+    d.tap_mask, d.slope = tap_mask, slope
     from . import functional as F_
     if F_.FORCE_IGEMM is not None:
         d.force_bm = F_.FORCE_IGEMM[0]  # the N tile follows from the channel count on this path
@@ -122,11 +122,19 @@ def _colsum_bf16(t2d, P, Cc):
     return out
 
 
+def _leaky_bwd_bf16(y, dy, slope):
+    dx = torch.empty_like(y)
+    L.check(L.load().lic_leaky_bwd_bf16(_ptr(y), _ptr(dy), _ptr(dx), y.numel(), slope, _stream()), "lic_leaky_bwd_bf16")
+    return dx
+
+
 class _ConvBF16Fn(torch.autograd.Function):
-    """nn.Conv2d / nn.ConvTranspose2d with bf16 activations (Components.py:12-16,39-43)."""
+    """nn.Conv2d / nn.ConvTranspose2d with bf16 activations (Components.py:12-16,39-43), optionally with the
+    LeakyReLU behind it fused (hyper / entropy-parameter layers: Components.py:69-73,99-103;
+    ParametersModels.py:22-34) and a tap mask (ContextModels.py:19-20)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, out_pad, transposed, out_f32):
+    def forward(ctx, x, weight, bias, stride, pad, out_pad, transposed, out_f32, leaky=False, slope=0.01, tap_mask=0):
         _check(x, weight, bias)
         xh = _as_bf16_nhwc(x)
         B, Hi, Wi, Cin = xh.shape
@@ -135,17 +143,22 @@ class _ConvBF16Fn(torch.autograd.Function):
         Ho, Wo = conv_out_size(Hi, Wi, kh, stride, pad, transposed, out_pad)
         wp = _pack_conv_weight_bf16(weight, transposed, False)
         out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32 if out_f32 else BF16)
+        if leaky and out_f32:
+            raise NotImplementedError("the fused LeakyReLU keeps its mask in the bf16 output")
         _igemm_bf16(xh, wp, out, B=B, Hi=Hi, Wi=Wi, Cin=Cin, Ho=Ho, Wo=Wo, Cout=Cout, kh=kh, kw=kw, stride=stride,
-                    pad=pad, transposed=transposed, bias=bias)
-        ctx.save_for_backward(xh, weight)
-        ctx.cfg = (stride, pad, transposed, bias is not None, x.dtype)
+                    pad=pad, transposed=transposed, bias=bias, epilogue=L.EPI_LEAKY if leaky else L.EPI_NONE,
+                    slope=slope, tap_mask=tap_mask)
+        ctx.save_for_backward(xh, weight, out if leaky else None)
+        ctx.cfg = (stride, pad, transposed, bias is not None, x.dtype, leaky, slope, tap_mask)
         return _nchw_view(out)
 
     @staticmethod
     def backward(ctx, gy):
-        xh, weight = ctx.saved_tensors
-        stride, pad, transposed, has_bias, in_dtype = ctx.cfg
+        xh, weight, yh = ctx.saved_tensors
+        stride, pad, transposed, has_bias, in_dtype, leaky, slope, tap_mask = ctx.cfg
         g = _as_bf16_nhwc(gy)
+        if leaky:
+            g = _leaky_bwd_bf16(yh, g, slope)
         B, Hi, Wi, Cin = xh.shape
         _, Ho, Wo, Cout = g.shape
         kh, kw = weight.shape[2], weight.shape[3]
@@ -155,7 +168,7 @@ class _ConvBF16Fn(torch.autograd.Function):
             wp = _pack_conv_weight_bf16(weight, transposed, True)
             dxh = torch.empty((B, Hi, Wi, Cin), device=g.device, dtype=in_dtype)
             _igemm_bf16(g, wp, dxh, B=B, Hi=Ho, Wi=Wo, Cin=Cout, Ho=Hi, Wo=Wi, Cout=Cin, kh=kh, kw=kw, stride=stride,
-                        pad=pad, transposed=not transposed)
+                        pad=pad, transposed=not transposed, tap_mask=tap_mask)
             dx = _nchw_view(dxh)
         if ctx.needs_input_grad[1]:
             dw = grad_like(weight)
@@ -167,7 +180,7 @@ class _ConvBF16Fn(torch.autograd.Function):
                             pad=pad, g_is_row=True, dst_sm=taps, dst_sn=Cin * taps, dst_stap=1)
         if has_bias and ctx.needs_input_grad[2]:
             db = _colsum_bf16(g, B * Ho * Wo, Cout)
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None
 
 
 def _kpad8(kh, kw, c):
@@ -351,12 +364,12 @@ class _GDNBF16Fn(torch.autograd.Function):
         return dx, dbeta, dgamma, None, None, None, None
 
 
-def conv2d_bf16(x, weight, bias, stride, padding, out_f32=False):
-    return _ConvBF16Fn.apply(x, weight, bias, stride, padding, 0, False, out_f32)
+def conv2d_bf16(x, weight, bias, stride, padding, out_f32=False, leaky=False, slope=0.01, tap_mask=0):
+    return _ConvBF16Fn.apply(x, weight, bias, stride, padding, 0, False, out_f32, leaky, slope, tap_mask)
 
 
-def conv_transpose2d_bf16(x, weight, bias, stride, padding, output_padding, out_f32=False):
-    return _ConvBF16Fn.apply(x, weight, bias, stride, padding, output_padding, True, out_f32)
+def conv_transpose2d_bf16(x, weight, bias, stride, padding, output_padding, out_f32=False, leaky=False, slope=0.01):
+    return _ConvBF16Fn.apply(x, weight, bias, stride, padding, output_padding, True, out_f32, leaky, slope, 0)
 
 
 def image_conv2d_bf16(x, weight, bias, stride, padding):

@@ -29,12 +29,14 @@ class Conv2d(nn.Conv2d):
         if self.groups != 1 or _pair(self.dilation) != 1:
             raise NotImplementedError("groups/dilation are not used by the reference models")
         s, p = _pair(self.stride), _pair(self.padding)
-        if bf16:  # bf16-storage path (BASELINE config 3): plain conv + bias only
-            if leaky or residual is not None:
-                raise NotImplementedError("bf16 mode covers the 5x5 conv/GDN stacks")
+        if bf16:  # bf16-storage path (BASELINE config 3): conv + bias (+ fused LeakyReLU)
+            if residual is not None:
+                raise NotImplementedError("bf16 mode covers the 5x5 conv/GDN stacks and the latent-side layers")
             if self.in_channels < 4:
+                if leaky:
+                    raise NotImplementedError
                 return FB_.image_conv2d_bf16(x, self.weight, self.bias, s, p)
-            return FB_.conv2d_bf16(x, self.weight, self.bias, s, p, out_f32)
+            return FB_.conv2d_bf16(x, self.weight, self.bias, s, p, out_f32, leaky, slope)
         if self.in_channels < 4:  # RGB stem: im2col + dense MFMA GEMM
             y = F_.image_conv2d(x, self.weight, self.bias, s, p, leaky, slope)
             return y if residual is None else y + residual
@@ -48,11 +50,13 @@ class ConvTranspose2d(nn.ConvTranspose2d):
             raise NotImplementedError("groups/dilation are not used by the reference models")
         s, p, op = _pair(self.stride), _pair(self.padding), _pair(self.output_padding)
         if bf16:
-            if leaky or residual is not None:
-                raise NotImplementedError("bf16 mode covers the 5x5 conv/GDN stacks")
+            if residual is not None:
+                raise NotImplementedError("bf16 mode covers the 5x5 conv/GDN stacks and the latent-side layers")
             if self.out_channels < 4:
+                if leaky:
+                    raise NotImplementedError
                 return FB_.image_conv_transpose2d_bf16(x, self.weight, self.bias, s, p, op)
-            return FB_.conv_transpose2d_bf16(x, self.weight, self.bias, s, p, op, out_f32)
+            return FB_.conv_transpose2d_bf16(x, self.weight, self.bias, s, p, op, out_f32, leaky, slope)
         if self.out_channels < 4:  # RGB head: dense MFMA GEMM + col2im
             if leaky or residual is not None:
                 raise NotImplementedError
@@ -72,17 +76,27 @@ class LeakyReLU(nn.Module):
         return F_.leaky_relu(x, self.negative_slope)
 
 
-def run_bf16(seq: nn.Sequential, x: Tensor) -> Tensor:
-    """bf16-storage execution of a conv/GDN stack: bf16 between layers, fp32 out of the last one."""
+def run_bf16(seq: nn.Sequential, x: Tensor, out_f32: bool = True) -> Tensor:
+    """bf16-storage execution of a stack: bf16 between layers (Conv -> LeakyReLU pairs as one launch), the
+    last layer writes fp32 when `out_f32` (latents, entropy parameters, the image) and bf16 otherwise
+    (features that only feed another bf16 layer)."""
     mods = list(seq)
-    for i, m in enumerate(mods):
+    i = 0
+    while i < len(mods):
+        m = mods[i]
+        nxt = mods[i + 1] if i + 1 < len(mods) else None
         if isinstance(m, (Conv2d, ConvTranspose2d)):
-            x = m(x, bf16=True, out_f32=(i == len(mods) - 1))
+            if isinstance(nxt, LeakyReLU):
+                x = m(x, bf16=True, leaky=True, slope=nxt.negative_slope)
+                i += 2
+                continue
+            x = m(x, bf16=True, out_f32=(out_f32 and i == len(mods) - 1))
         elif isinstance(m, GDN):
             x = m(x, bf16=True)
         else:
             raise NotImplementedError(f"bf16 mode does not cover {type(m).__name__}")
-    return x.float() if x.dtype != torch.float32 else x
+        i += 1
+    return x.float() if (out_f32 and x.dtype != torch.float32) else x
 
 
 # conv -> GDN pairs as one launch: "auto" = where it is measured to pay (layers on 64-row tiles),

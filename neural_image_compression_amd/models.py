@@ -38,16 +38,22 @@ class _HyperpriorContextModel(nn.Module):
         self.entropy_parameters = EntropyParameters(latent_channels=self.M, hyper_latent_channels=self.H,
                                                     K=self.K)
 
-    def set_precision(self, precision: str = "fp32"):
-        """"fp32" (default, the reference's arithmetic) or "bf16": bf16 activation storage and bf16 MFMA
-        with fp32 accumulation inside the analysis / synthesis stacks (BASELINE config 3; not in the
-        reference).  Latents, hyper path, likelihoods and the loss stay fp32."""
-        if precision not in ("fp32", "bf16"):
-            raise ValueError(f"precision must be 'fp32' or 'bf16', got {precision!r}")
-        if precision == "bf16" and not isinstance(self.encoder, Encoder5x5):
-            raise NotImplementedError("bf16 mode covers the 5x5 conv/GDN stacks (JointAutoregressiveHierarchical)")
-        self.encoder.precision = precision
-        self.decoder.precision = precision
+    def set_precision(self, precision: str = "fp32", latent: str = None):
+        """"fp32" (default, the reference's arithmetic) or "bf16": bf16 activation storage and bf16 MFMA with
+        fp32 accumulation (BASELINE config 3; not in the reference) in the analysis / synthesis
+        stacks and -- `latent`, default = `precision` -- in the hyper encoder / decoder, the context model and
+        the entropy-parameter MLP.  The latents y, z, the raw entropy parameters, quantisation, every
+        likelihood and the loss stay fp32; parameters and their gradients are always fp32."""
+        latent = precision if latent is None else latent
+        for v in (precision, latent):
+            if v not in ("fp32", "bf16"):
+                raise ValueError(f"precision must be 'fp32' or 'bf16', got {v!r}")
+        if "bf16" in (precision, latent) and not isinstance(self.encoder, Encoder5x5):
+            raise NotImplementedError("bf16 mode covers the 5x5 model (JointAutoregressiveHierarchical)")
+        self.encoder.precision = self.decoder.precision = precision
+        for m in (self.hyper_encoder, self.hyper_decoder, self.context_model, self.entropy_parameters):
+            m.precision = latent
+        self.hyper_decoder.out_f32 = latent != "bf16"   # psi feeds the bf16 MLP directly
         return self
 
     def analysis_hyperprior(self, x: torch.Tensor, training: bool = True, noise=None, with_packed_params=False,

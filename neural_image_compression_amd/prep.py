@@ -23,6 +23,8 @@ from . import functional as F_
 from .layers import Conv2d, ConvTranspose2d, GDN
 
 BF16 = torch.bfloat16
+# sub-modules of the models that carry a `precision` attribute (models.set_precision)
+_PRECISION_OWNERS = ("encoder", "decoder", "hyper_encoder", "hyper_decoder", "context_model", "entropy_parameters")
 
 
 def _drop(keys):
@@ -50,13 +52,13 @@ class StepPrep:
     # ------------------------------------------------------------------------------------------
     def _signature(self):
         m = self.model
-        prec = tuple(getattr(getattr(m, n, None), "precision", "fp32") for n in ("encoder", "decoder"))
+        prec = tuple(getattr(getattr(m, n, None), "precision", "fp32") for n in _PRECISION_OWNERS)
         p0 = next(m.parameters())
         return (p0.device, prec, tuple(p.data_ptr() for p in m.parameters()))
 
     def _bf16_modules(self):
         ids = set()
-        for n in ("encoder", "decoder"):
+        for n in _PRECISION_OWNERS:
             st = getattr(self.model, n, None)
             if st is not None and getattr(st, "precision", "fp32") == "bf16":
                 ids.update(id(q) for q in st.modules())
