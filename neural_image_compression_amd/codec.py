@@ -16,6 +16,7 @@ already-decoded pixels through the masked 5x5 context model, wavefront by wavefr
 from __future__ import annotations
 
 import ctypes as C
+import zlib
 import os
 from typing import Dict
 
@@ -274,9 +275,9 @@ class ContextCodec:
         """windows [N, 12M, 1, 1], psi_px [N, 2M, 1, 1] -> (center [N, M], tables [N*M, S+1]) on the device"""
         m = self.model
         wp, b, co, _, _ = layers[0]
-        x = torch.cat([F_.conv2d_prepacked(windows, wp, b, co, 1), psi_px], dim=1)
+        x = torch.cat([F_.conv2d_prepacked(windows, wp, b, co, 1, pin_tile=True), psi_px], dim=1)
         for wp, b, co, leaky, slope in layers[1:]:
-            x = F_.conv2d_prepacked(x, wp, b, co, 1, leaky=leaky, slope=slope)
+            x = F_.conv2d_prepacked(x, wp, b, co, 1, leaky=leaky, slope=slope, pin_tile=True)
         act = F_.entropy_params_activation(x, m.M, m.K)
         return gmm_tables(act, m.M, m.K, self.y_W)
 
@@ -298,7 +299,7 @@ class ContextCodec:
         zt = factorized_tables(m.factorized_entropy_model, self.z_lo, self.z_S).cpu().numpy().view(np.uint32)
         z_idx = (z_in.permute(0, 2, 3, 1).contiguous().round().to(torch.int32) - self.z_lo).cpu().numpy().ravel()
         z_bytes = rc_encode(zt, z_idx, np.tile(np.arange(M, dtype=np.int32), z_idx.size // M))
-        psi = m.hyper_decoder(z_in)
+        psi = m.hyper_decoder(z_in).float()
         psi_px = psi.permute(0, 2, 3, 1).reshape(B * h * w, -1, 1, 1).contiguous()
         center, tables = self._params_at(self._windows_all(y_in), psi_px, self._prepack())
         y_sym = y_in.permute(0, 2, 3, 1).reshape(B * h * w, M).round().to(torch.int32)
@@ -310,7 +311,12 @@ class ContextCodec:
         npix = x.shape[0] * x.shape[2] * x.shape[3]
         coded = 8.0 * (len(z_bytes) + sum(len(s) for s in y_streams)) / npix
         est = float(-(out["logp_y"].double().sum() + out["logp_z"].double().sum()) / np.log(2.0) / npix)
-        return {"strings": {"y": y_streams, "z": z_bytes}, "shape": (B, M, h, w), "z_shape": tuple(z_in.shape),
+        # CRC-32 of every image's latent symbols: a decoder whose tables differ from the encoder's by one count
+        # decodes garbage silently; with the checksum it fails loudly instead
+        y_crc = [zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
+                 for a in y_sym.view(B, h * w * M).cpu().numpy().astype(np.int32)]
+        return {"strings": {"y": y_streams, "z": z_bytes, "y_crc32": y_crc}, "shape": (B, M, h, w),
+                "z_shape": tuple(z_in.shape),
                 "bpp_coded": coded, "bpp_est": est, "y_in": y_in, "z_in": z_in}
 
     @torch.no_grad()
@@ -320,7 +326,7 @@ class ContextCodec:
         dev = next(m.parameters()).device
         z_hat = LatentCodec(m, self.z_lo, self.z_S, self.y_W).decompress_z(strings["z"], z_shape)
         z_hat = z_hat.contiguous(memory_format=torch.channels_last)
-        psi = m.hyper_decoder(z_hat)
+        psi = m.hyper_decoder(z_hat).float()
         layers = self._prepack()
         p = self.pad
         S1 = 2 * self.y_W + 2
@@ -363,6 +369,12 @@ class ContextCodec:
         finally:
             for d in decs:
                 d.close()
+        if "y_crc32" in strings:
+            got = ypad[:, p:p + h, p:p + w, :].reshape(B, h * w * M).round().to(torch.int32).cpu().numpy()
+            for b in range(B):
+                if (zlib.crc32(np.ascontiguousarray(got[b]).tobytes()) & 0xFFFFFFFF) != int(strings["y_crc32"][b]):
+                    raise CodecError(f"image {b}: decoded latents do not match the encoder's checksum "
+                                     "(encoder and decoder built different probability tables, or the stream is damaged)")
         y_hat = ypad[:, p:p + h, p:p + w, :].permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
         x_hat = m.decoder(y_hat)
         return {"x_hat": x_hat, "y_hat": y_hat, "z_hat": z_hat}

@@ -61,6 +61,11 @@ def _require_cuda(*ts):
         if t is not None and not t.is_cuda:
             raise L.LicError("neural_image_compression_amd runs on MI355X only: got a non-CUDA tensor "
                              "(there is no CPU fallback; the CPU oracle lives in oracle/ for tests)")
+        if t is not None and t.device.index != torch.cuda.current_device():
+            # kernels are launched on the CURRENT device's stream (_stream): a tensor of another GPU would be
+            # read through the wrong device's queue
+            raise L.LicError(f"tensor on cuda:{t.device.index} but the current device is cuda:"
+                             f"{torch.cuda.current_device()}: call torch.cuda.set_device(...) first (one process per GPU)")
         if t is not None and t.dtype != torch.float32:
             raise L.LicError(f"fp32 tensors expected, got {t.dtype}")
 
@@ -342,7 +347,8 @@ def pack_conv_weight(weight: torch.Tensor) -> torch.Tensor:
 
 
 @torch.no_grad()
-def conv2d_prepacked(x, w_packed, bias, cout, kernel, stride=1, padding=0, leaky=False, slope=0.01, tap_mask=0):
+def conv2d_prepacked(x, w_packed, bias, cout, kernel, stride=1, padding=0, leaky=False, slope=0.01, tap_mask=0,
+                     pin_tile=False):
     """Inference-only conv2d whose weight was packed once with `pack_conv_weight` (no autograd, no per-call
     packing): same kernel, same operands, hence the same bits as `conv2d`.  The serial context decoder calls
     four layers h*w times with unchanged weights (codec.ContextCodec)."""
@@ -351,9 +357,19 @@ def conv2d_prepacked(x, w_packed, bias, cout, kernel, stride=1, padding=0, leaky
     B, Hi, Wi, Cin = xh.shape
     Ho, Wo = conv_out_size(Hi, Wi, kernel, stride, padding, False)
     out = torch.empty((B, Ho, Wo, cout), device=x.device, dtype=torch.float32)
-    _igemm(xh, w_packed, out, B=B, Hi=Hi, Wi=Wi, Cin=Cin, Ho=Ho, Wo=Wo, Cout=cout, kh=kernel, kw=kernel,
-           stride=stride, pad=padding, transposed=False, bias=bias,
-           epilogue=L.EPI_LEAKY if leaky else L.EPI_NONE, slope=slope, tap_mask=tap_mask)
+    global FORCE_IGEMM
+    saved = FORCE_IGEMM
+    if pin_tile and Cin % 4 == 0 and cout % 64 == 0:
+        # one tile variant whatever the batch (the entropy coder's encoder sees all pixels at once, its decoder a
+        # wavefront of them).  Every variant accumulates an output element over K in the same order, so they
+        # agree bit for bit by construction; pinning just stops the agreement from resting on that argument.
+        FORCE_IGEMM = (64, 1, 0)
+    try:
+        _igemm(xh, w_packed, out, B=B, Hi=Hi, Wi=Wi, Cin=Cin, Ho=Ho, Wo=Wo, Cout=cout, kh=kernel, kw=kernel,
+               stride=stride, pad=padding, transposed=False, bias=bias,
+               epilogue=L.EPI_LEAKY if leaky else L.EPI_NONE, slope=slope, tap_mask=tap_mask)
+    finally:
+        FORCE_IGEMM = saved
     return _nchw_view(out)
 
 

@@ -157,15 +157,18 @@ def test_coded_bpp_matches_estimate_and_round_trips(codec, K):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("K,B,H,W,kind", [(1, 2, 64, 128, "jah"), (3, 1, 128, 64, "jah"), (3, 2, 64, 192, "hmr")])
-def test_context_codec_full_round_trip(codec, K, B, H, W, kind):
+@pytest.mark.parametrize("K,B,H,W,kind,M", [(1, 2, 64, 128, "jah", 32), (3, 1, 128, 64, "jah", 32), (3, 2, 64, 192, "hmr", 32),
+                                            (1, 3, 128, 128, "jah", 64), (3, 1, 192, 64, "jah", 64), (3, 4, 64, 256, "jah", 64)])
+def test_context_codec_full_round_trip(codec, K, B, H, W, kind, M):
     """compress -> bytes -> decompress through the masked-conv context (wavefront schedule): the decoded
     latents equal the encoder's exactly, x_hat equals the model's eval output, coded ~ estimated."""
     if not torch.cuda.is_available():
         pytest.skip("needs an MI355X")
     import neural_image_compression_amd as nic
     import golden_recipe as R
-    M = 32
+    # M = 64: every per-pixel layer is 64-column tileable, so the coder pins ONE igemm tile (conv2d_prepacked
+    # pin_tile) while the encoder (B*h*w pixels at once) and the decoder (a wavefront of <= B*h pixels per step)
+    # would otherwise pick tiles by their very different batch sizes
     model = (nic.JointAutoregressiveHierarchical if kind == "jah" else nic.HierarchicalMixtureResidual)(M, K)
     st = R.make_state([(k, tuple(v.shape)) for k, v in model.state_dict().items()], 51)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
@@ -182,6 +185,11 @@ def test_context_codec_full_round_trip(codec, K, B, H, W, kind):
     assert torch.equal(dec["x_hat"], ref["x_hat"])
     npix = B * H * W
     assert abs(enc["bpp_coded"] - enc["bpp_est"]) <= 0.02 * enc["bpp_est"] + (64.0 * (B + 1)) / npix
+    # the stream carries a CRC-32 of each image's latent symbols: a mismatch is reported, not decoded silently
+    assert len(enc["strings"]["y_crc32"]) == B
+    bad = dict(enc["strings"], y_crc32=[c ^ 1 for c in enc["strings"]["y_crc32"]])
+    with pytest.raises(codec.CodecError):
+        cc.decompress(bad, enc["shape"], enc["z_shape"])
 
 
 @pytest.mark.gpu
