@@ -10,10 +10,9 @@
  * Conventions
  *  - All pointers are DEVICE pointers to fp32 unless stated.  Activations are NHWC: element
  *    (b,h,w,c) of a tensor with row pitch `ld` (floats per pixel, ld >= C) lives at
- *    ((b*H + h)*W + w)*ld + c.  `ld` lets two producers write disjoint channel ranges of one
- *    buffer: the reference's torch.cat([phi, psi]) (Models.py:73) is not materialised in the fp32
- *    path -- the context conv and the hyper decoder's last conv write the two halves of one tensor
- *    (models.py; the backward's two gradient slices are still made contiguous by a copy each).
+ *    ((b*H + h)*W + w)*ld + c.  `ld` lets a producer write a channel range of a wider buffer and a
+ *    consumer read one (strided views).  (The host layer still materialises the reference's
+ *    torch.cat([phi, psi]), Models.py:73, as one 25 MB device copy per step: models.py.)
  *  - The library never allocates, frees or synchronises; every launch goes to `stream`
  *    (a hipStream_t passed as void*), so every call is hipGraph-capturable.  Workspaces are
  *    caller-owned; sizes come from the *_workspace_bytes queries.
@@ -110,13 +109,6 @@ typedef struct lic_igemm_desc {
    *   ceil32(Cout) % (64*force_tn) == 0, else LIC_ERR_UNSUPPORTED); force_split >= 1: K splits
    *   (1 = never split; needs `workspace`). */
   int32_t force_bm, force_tn, force_split, reserved0;
-  /* Optional, split-K launches only: `tickets_len` int32 counters that are ZERO on entry (one per output tile
-   * is used; the launch leaves them zero again).  With them the K splits of a tile are summed inside the
-   * kernel -- the workgroup that arrives last at its tile's ticket adds the slabs in slab order and runs the
-   * fused epilogue -- instead of by a second launch; same bits either way.  Launches that may run
-   * concurrently (different streams) must not share tickets. */
-  int32_t* tickets;
-  int64_t tickets_len;
 } lic_igemm_desc;
 
 /* 1 when lic_igemm can run LIC_EPI_CONV_GDN / LIC_EPI_CONV_IGDN for these channel counts
@@ -168,10 +160,6 @@ typedef struct lic_wgrad_desc {
    * (1,1) (1,3) (2,1) (2,2) (2,3) (3,3) -- (3,3) needs both channel counts % 192 == 0 -- and the number
    * of pixel splits */
   int32_t force_tm, force_tn, force_split;
-  /* optional zeroed arrival counters, as in lic_igemm_desc: the pixel splits of a (tile, tap) are then summed
-   * and scattered to `dst` by the last workgroup to arrive instead of by a second launch */
-  int32_t* tickets;
-  int64_t tickets_len;
 } lic_wgrad_desc;
 
 size_t lic_wgrad_workspace_bytes(const lic_wgrad_desc* d);

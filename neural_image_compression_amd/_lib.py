@@ -29,8 +29,7 @@ class IgemmDesc(C.Structure):
                 ("transposed", _i32), ("prologue", _i32), ("epilogue", _i32),
                 ("tap_mask", C.c_uint32), ("slope", _f32), ("workspace", _vp), ("workspace_bytes", _sz),
                 ("out3", _vp), ("out3_ld", _i64),
-                ("force_bm", _i32), ("force_tn", _i32), ("force_split", _i32), ("reserved0", _i32),
-                ("tickets", _vp), ("tickets_len", _i64)]
+                ("force_bm", _i32), ("force_tn", _i32), ("force_split", _i32), ("reserved0", _i32)]
 
 
 class WgradDesc(C.Structure):
@@ -41,8 +40,7 @@ class WgradDesc(C.Structure):
                 ("Hl", _i32), ("Wl", _i32), ("Cg", _i32),
                 ("kh", _i32), ("kw", _i32), ("stride", _i32), ("pad", _i32),
                 ("g_is_row", _i32), ("sq_p", _i32), ("sq_g", _i32), ("scale", _f32),
-                ("force_tm", _i32), ("force_tn", _i32), ("force_split", _i32),
-                ("tickets", _vp), ("tickets_len", _i64)]
+                ("force_tm", _i32), ("force_tn", _i32), ("force_split", _i32)]
 
 
 PREP_PACK_F32, PREP_PACK_BF16, PREP_MAP, PREP_MASK_INPLACE = range(4)

@@ -65,7 +65,6 @@ struct IgemmParams {
   int ksplit;  // >1: K (the chunk list) is split across workgroups; raw partial sums go to `slabs`
   int cps;     // chunks per split
   float* slabs;  // [ksplit][B*Ho*Wo][Cout] fp32
-  int* tickets;  // split-K: one arrival counter per output tile (zero before and after the launch), or null
   int MT, NT;  // tiles in M (max over phases) and N
   int bm_unfused;  // host-side note: the M tile the same launch would use without a fused GDN
   int pgroup;      // 4-phase launches: M tiles per phase-sorted group (0 = rotate phases tile by tile)
@@ -128,7 +127,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
   // phases (their K lengths differ up to 2.25x: 9/6/6/4 taps for 5x5 stride 2)
   const int ks = wg % p.ksplit;  // K split fastest: the splits of a tile share its A rows in L2
   wg /= p.ksplit;
-  const int tile_id = wg;        // (phase, M tile, N tile): the unit the K splits of a launch meet on
   const int nt = wg % p.NT;
   const int kq = wg / p.NT;
   // Rotate the phase order from one M tile to the next.  Phase durations differ (9/6/6/4 taps)
@@ -668,53 +666,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
           if (col < p.Cout) slab[opix * p.Cout + col] = acc[a][b][r];
         }
       }
-    if (p.tickets == nullptr) return;  // igemm_finish*_kernel sums the slabs
-    // In-kernel reduction: the workgroup that arrives LAST at its tile's ticket sums the ksplit slabs of the
-    // tile -- its own included -- in slab order (the order igemm_finish*_kernel uses: same bits whichever
-    // workgroup is last) into its accumulators and runs the normal fused epilogue.  Release / acquire fences
-    // at agent scope make the other XCDs' slab stores visible; the ticket is left at zero for the next launch.
-    // (the flag lives in the tail of the one staging array: a second __shared__ object would cost the DMA loop
-    // a vmcnt(0) in front of every LDS read, see s_taps)
-    volatile int* s_last = reinterpret_cast<volatile int*>(smem + SA_FLOATS) + 30;
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) *s_last = (atomicAdd(&p.tickets[tile_id], 1) == p.ksplit - 1) ? 1 : 0;
-    __syncthreads();
-    if (!*s_last) return;
-    __threadfence();
-    if (tid == 0) p.tickets[tile_id] = 0;
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-      for (int b = 0; b < TN; ++b)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
-    const long slab_stride = (long)p.B * p.Ho * p.Wo * p.Cout;
-#pragma unroll
-    for (int a = 0; a < TM; ++a)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int prow = m0 + wm0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (prow >= P) continue;
-        long opix = prow;
-        if (p.nphase > 1) {
-          const int b = fdiv(prow, p.dHW[phase]);
-          const int rem = prow - b * Hq * Wq;
-          const int i = fdiv(rem, p.dW[phase]), jj = rem - i * Wq;
-          opix = ((long)b * p.Ho + i * sph + py) * p.Wo + jj * sph + px;
-        }
-#pragma unroll
-        for (int b = 0; b < TN; ++b) {
-          const int col = n0 + wn0 + b * 32 + li;
-          if (col >= p.Cout) continue;
-          const float* sp = p.slabs + opix * p.Cout + col;
-          float v = 0.0f;
-          for (int z = 0; z < p.ksplit; ++z)  // agent-scope loads: never served from a stale line of this XCD's L2
-            v += __hip_atomic_load(sp + (long)z * slab_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          acc[a][b][r] = v;
-        }
-      }
-    __syncthreads();  // (the staged epilogue below reuses LDS that s_last's neighbours may still be reading)
+    return;
   }
   const int epi = p.epilogue;
   if (p.vec_out) {
@@ -1021,24 +973,6 @@ LIC_EXPORT int lic_igemm_fused_gdn_supported(int32_t Cin, int32_t Cout) {
   return (Cout == 64 || Cout == 128 || Cout == 192) && Cin > 0 && Cin % 4 == 0;
 }
 
-// K-split factor of a launch (1 = no split).  A function of per-image geometry only -- never of the batch
-// size or of the tile -- so an image's result does not depend on which batch it is computed in (bitwise
-// batch-split invariance: the split changes the summation order, the tile does not).
-static long igemm_geo_split(const lic_igemm_desc* d, int Npad, int max_chunks, int epi, bool fuse) {
-  const bool simple_epi = (epi == LIC_EPI_NONE || epi == LIC_EPI_LEAKY) && !d->res && !d->out2 && d->prologue < 2;
-  const long t_img = (((long)d->Ho * d->Wo + 63) / 64) * ((Npad + 63) / 64);
-  const char* env_split = d->force_split > 0 ? nullptr : getenv("LIC_IGEMM_FORCE_SPLIT");
-  if (!(simple_epi && !fuse && d->workspace && (t_img < 40 || env_split || d->force_split > 1) && d->force_split != 1 &&
-        (max_chunks >= 16 || d->force_split > 1)))
-    return 1;
-  long S = (40 + t_img - 1) / t_img;
-  if (S > max_chunks / 8) S = max_chunks / 8;  // at least 8 chunks per split
-  if (S > 32) S = 32;
-  if (env_split) S = atoi(env_split);  // tuning aid
-  if (d->force_split > 1) S = d->force_split < max_chunks ? d->force_split : max_chunks;
-  return S > 1 ? S : 1;
-}
-
 // fills the kernel parameter block; returns LIC_OK, or 1 when there is nothing to launch
 static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& TN, long& nwg,
                          int64_t& live_macs) {
@@ -1158,13 +1092,6 @@ static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& 
   int best = 5;
   long best_wg = -1;
   bool found = false;
-  // Small layers get their K loop split across workgroups (below).  The split factor depends on per-image
-  // geometry only -- never on the tile -- so it is known here, and a full-N tile may count its splits as
-  // workgroups: the 16x16 latent layers then take 64x192 tiles (activations gathered once per 192 columns)
-  // instead of 64x64 ones (measured stand-alone: context / hyper-decoder 3x3 layers -10..-17 %).
-  int max_chunks0 = 0;
-  for (int ph = 0; ph < p.nphase; ++ph) max_chunks0 = p.ntaps[ph] * p.cpt > max_chunks0 ? p.ntaps[ph] * p.cpt : max_chunks0;
-  const long S_geo = igemm_geo_split(d, p.Npad, max_chunks0, epi, fuse);
   // first pass: shapes whose N tiling comes out full (branch-free MFMA block); second: any
   for (int pass = 0; pass < 2 && !found; ++pass)
     for (int c = 0; c < 6; ++c) {
@@ -1175,8 +1102,7 @@ static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& 
       if (bm == 128 && max_taps * p.cpt <= 16) continue;
       if (p.Npad < 64 * tn && tn > 1 && p.Npad <= 64 * (tn - 1)) continue;  // wider than the problem
       if (pass == 0 && p.Npad % (64 * tn) != 0) continue;
-      long wgs = ((maxP + bm - 1) / bm) * ((p.Npad + 64 * tn - 1) / (64 * tn)) * p.nphase;
-      if (pass == 0) wgs *= S_geo;
+      const long wgs = ((maxP + bm - 1) / bm) * ((p.Npad + 64 * tn - 1) / (64 * tn)) * p.nphase;
       if (wgs >= 512) {
         best = c;
         best_wg = wgs;
@@ -1235,12 +1161,21 @@ static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& 
   // split their K loop across workgroups when the caller provided a workspace.
   p.ksplit = 1;
   p.slabs = nullptr;
-  p.tickets = nullptr;
   int max_chunks = 0;
   for (int ph = 0; ph < p.nphase; ++ph) max_chunks = p.ntaps[ph] * p.cpt > max_chunks ? p.ntaps[ph] * p.cpt : max_chunks;
   p.cps = max_chunks > 0 ? max_chunks : 1;
-  {
-    const long S = igemm_geo_split(d, p.Npad, max_chunks, epi, fuse);
+  const bool simple_epi = (epi == LIC_EPI_NONE || epi == LIC_EPI_LEAKY) && !d->res && !d->out2 && d->prologue < 2;
+  // The split factor depends only on per-image geometry (never on the batch size), so an image's
+  // result does not depend on which batch it is computed in (bitwise batch-split invariance).
+  const long t_img = (((long)d->Ho * d->Wo + 63) / 64) * ((p.Npad + 63) / 64);
+  const char* env_split = d->force_split > 0 ? nullptr : getenv("LIC_IGEMM_FORCE_SPLIT");
+  if (simple_epi && !fuse && d->workspace && (t_img < 40 || env_split || d->force_split > 1) && d->force_split != 1 &&
+      (max_chunks >= 16 || d->force_split > 1)) {
+    long S = (40 + t_img - 1) / t_img;
+    if (S > max_chunks / 8) S = max_chunks / 8;  // at least 8 chunks per split
+    if (S > 32) S = 32;
+    if (env_split) S = atoi(env_split);  // tuning aid
+    if (d->force_split > 1) S = d->force_split < max_chunks ? d->force_split : max_chunks;
     if (S > 1) {
       p.cps = (int)((max_chunks + S - 1) / S);
       p.ksplit = (max_chunks + p.cps - 1) / p.cps;
@@ -1248,8 +1183,6 @@ static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& 
       if (d->workspace_bytes < need) return LIC_ERR_WORKSPACE;
       p.slabs = (float*)d->workspace;
       nwg *= p.ksplit;
-      // in-kernel reduction when the caller lent a zeroed ticket array that covers every output tile
-      if (d->tickets && d->tickets_len >= (long)p.MT * p.NT * p.nphase) p.tickets = d->tickets;
     }
   }
   if (nwg > 0x7FFFFFFFL) return LIC_ERR_UNSUPPORTED;
@@ -1376,7 +1309,7 @@ LIC_EXPORT int lic_igemm(const lic_igemm_desc* d, lic_stream_t stream) {
   else
     LIC_IGEMM_LAUNCH(64, 1);
 #undef LIC_IGEMM_LAUNCH
-  if (p.ksplit > 1 && p.tickets == nullptr) {
+  if (p.ksplit > 1) {
     int rc2 = lic_check_launch();
     if (rc2 != LIC_OK) return rc2;
     const long npix = (long)d->B * d->Ho * d->Wo;
@@ -1421,48 +1354,7 @@ struct WgradParams {
   int chunks_per_split, nchunks;
   long Ps;
   FastDiv dHW, dW;  // divide by Hs*Ws and by Ws
-  // in-kernel reduction (tickets != null): the last workgroup to arrive at a (tile, tap) sums the splitk slabs
-  // in slab order and scatters scale * sum to dst[m*sm + n*sn + tap*stap]
-  int* tickets;
-  int splitk;
-  float* dst;
-  long sm, sn, stap;
-  float scale;
 };
-
-// Shared tail of the wgrad kernels.  `flag`: one int of LDS nobody reads any more.  Returns after the slab
-// store when the launch has no tickets (wgrad_reduce_kernel follows) or this workgroup is not the last one.
-template <int TM, int TN>
-__device__ __forceinline__ void wgrad_finish(const WgradParams& p, volatile int* flag, int tile, int tap, int m0, int n0,
-                                             int wm0, int wn0, int li, int lh, int tid) {
-  if (p.tickets == nullptr) return;
-  __threadfence();   // release: this workgroup's slab tile is visible at agent scope
-  __syncthreads();
-  if (tid == 0) *flag = (atomicAdd(&p.tickets[tap * (p.MTt * p.NTt) + tile], 1) == p.splitk - 1) ? 1 : 0;
-  __syncthreads();
-  if (!*flag) return;
-  __threadfence();   // acquire
-  if (tid == 0) p.tickets[tap * (p.MTt * p.NTt) + tile] = 0;
-  const long slab_stride = (long)p.ntaps * p.row.C * p.col.C;
-  const float* base = p.slabs + (long)tap * p.row.C * p.col.C;
-#pragma unroll
-  for (int a = 0; a < TM; ++a)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int m = m0 + wm0 + a * 32 + (q & 3) + 8 * (q >> 2) + 4 * lh;
-      if (m >= p.row.C) continue;
-#pragma unroll
-      for (int b = 0; b < TN; ++b) {
-        const int n = n0 + wn0 + b * 32 + li;
-        if (n >= p.col.C) continue;
-        const float* sp = base + (long)m * p.col.C + n;
-        float v = 0.0f;
-        for (int z = 0; z < p.splitk; ++z)
-          v += __hip_atomic_load(sp + (long)z * slab_stride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        p.dst[m * p.sm + n * p.sn + tap * p.stap] = v * p.scale;
-      }
-    }
-}
 
 constexpr int WG_BK = 16;
 
@@ -1636,7 +1528,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradParams p) {
         if (n < p.col.C) slab[(long)m * p.col.C + n] = acc[a][b][q];
       }
     }
-  wgrad_finish<TM, TN>(p, reinterpret_cast<volatile int*>(&sA[0][0]), tile, tap, m0, n0, wm0, wn0, li, lh, tid);
 }
 
 // LDS-DMA variant of wgrad_kernel for full tiles: both operands go
@@ -1771,7 +1662,6 @@ __global__ __launch_bounds__(256, (TM * TN >= 6 ? 2 : 1)) void wgrad_glds_kernel
         if (FULL || n < p.col.C) slab[(long)m * p.col.C + n] = acc[a][b][q];
       }
     }
-  wgrad_finish<TM, TN>(p, reinterpret_cast<volatile int*>(&smem[0][0][0]), tile, tap, m0, n0, wm0, wn0, li, lh, tid);
 }
 
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* slabs, float* dst, int splitk,
@@ -1965,13 +1855,6 @@ static int wgrad_run(const lic_wgrad_desc* d, void* workspace, size_t workspace_
   p.Ps = (long)d->B * d->Hs * d->Ws;
   p.dHW = make_fastdiv((unsigned)(d->Hs * d->Ws));
   p.dW = make_fastdiv((unsigned)d->Ws);
-  p.splitk = pl.splitk;
-  p.dst = d->dst;
-  p.sm = d->dst_sm;
-  p.sn = d->dst_sn;
-  p.stap = d->dst_stap;
-  p.scale = d->scale;
-  p.tickets = (d->tickets && d->tickets_len >= (long)pl.MTt * pl.NTt * pl.ntaps) ? d->tickets : nullptr;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid(pl.MTt * pl.NTt * pl.ntaps * pl.splitk), block(256);
   const bool full = (pl.Cm % (64 * pl.TM) == 0) && (pl.Cn % (64 * pl.TN) == 0);
@@ -2012,7 +1895,7 @@ static int wgrad_run(const lic_wgrad_desc* d, void* workspace, size_t workspace_
   rc = lic_check_launch();
   if (rc != LIC_OK) return rc;
   }
-  if (stage == 1 || p.tickets) return LIC_OK;  // (with tickets the MFMA kernel has reduced and scattered already)
+  if (stage == 1) return LIC_OK;
   const long total = (long)pl.ntaps * pl.Cm * pl.Cn;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, s,
                      (const float*)workspace, d->dst, pl.splitk, pl.ntaps, pl.Cm, pl.Cn, (long)d->dst_sm,

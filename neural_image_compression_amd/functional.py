@@ -10,7 +10,6 @@ No CPU fallback: a non-CUDA tensor or a missing extension raises.
 from __future__ import annotations
 
 import ctypes as C
-import os
 from typing import Optional, Tuple
 
 import torch
@@ -51,23 +50,6 @@ def _stream():
     if _raw_stream is not None:
         return C.c_void_p(_raw_stream(torch.cuda.current_device()))
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
-
-
-# Zeroed int32 arrival counters lent to split-K launches (lic.h: `tickets`): the kernels sum their K / pixel
-# splits themselves and leave the counters at zero, so one array per (device, stream) serves every launch of
-# that stream -- launches of one stream never overlap, launches of different streams never share an array.
-_TICKETS = {}
-_TICKETS_LEN = 1 << 16
-INKERNEL_REDUCE = os.environ.get("LIC_INKERNEL_REDUCE", "1") != "0"   # 0: separate finish / reduce launches (A/B)
-
-
-def _tickets():
-    dev = torch.cuda.current_device()
-    key = (dev, _raw_stream(dev) if _raw_stream is not None else torch.cuda.current_stream().cuda_stream)
-    t = _TICKETS.get(key)
-    if t is None:
-        t = _TICKETS[key] = torch.zeros(_TICKETS_LEN, dtype=torch.int32, device=torch.device("cuda", dev))
-    return t
 
 
 def _ptr(t: Optional[torch.Tensor]):
@@ -165,8 +147,6 @@ def _igemm(inp, w_packed, out, *, B, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, 
         if nbytes:
             ws = torch.empty(nbytes // 4, device=inp.device, dtype=torch.float32)
             d.workspace, d.workspace_bytes = _ptr(ws), nbytes
-            if INKERNEL_REDUCE:
-                d.tickets, d.tickets_len = _ptr(_tickets()), _TICKETS_LEN
     if PROFILE is None or 2.0 * B * Ho * Wo * Cout * Cin * kh * kw < PROFILE_MIN_FLOP:
         L.check(lib.lic_igemm(C.byref(d), _stream()), "lic_igemm")
         return
@@ -220,8 +200,6 @@ def _wgrad(p, g, dst, *, B, Hs, Ws, Cp, Hl, Wl, Cg, kh, kw, stride, pad, g_is_ro
         KERNEL_TRACE.add(_kernel_name(lib.lic_wgrad_kernel_name, d))
     nbytes = lib.lic_wgrad_workspace_bytes(C.byref(d))
     ws = torch.empty((max(nbytes, 4) + 3) // 4, device=p.device, dtype=torch.float32)
-    if INKERNEL_REDUCE:
-        d.tickets, d.tickets_len = _ptr(_tickets()), _TICKETS_LEN
     if PROFILE is None or 2.0 * B * Hs * Ws * kh * kw * Cp * Cg < PROFILE_MIN_FLOP:
         L.check(lib.lic_wgrad(C.byref(d), _ptr(ws), nbytes, _stream()), "lic_wgrad")
         return
@@ -288,7 +266,7 @@ class _ConvFn(torch.autograd.Function):
     ParametersModels.py:22-34; ContextModels.py:19-20."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, out_pad, transposed, leaky, slope, tap_mask, res, out_view=None):
+    def forward(ctx, x, weight, bias, stride, pad, out_pad, transposed, leaky, slope, tap_mask, res):
         _require_cuda(x, weight, bias, res)
         xh = _nhwc(x)
         B, Hi, Wi, Cin = xh.shape
@@ -296,22 +274,14 @@ class _ConvFn(torch.autograd.Function):
         Cout = weight.shape[1] if transposed else weight.shape[0]
         Ho, Wo = conv_out_size(Hi, Wi, kh, stride, pad, transposed, out_pad)
         wp = _pack_conv_weight(weight, transposed, for_dgrad=False)
-        out_ld = None
-        if out_view is not None:
-            # the caller's channel range of a wider NHWC buffer (two producers fill one tensor: no torch.cat)
-            if leaky or res is not None or tuple(out_view.shape) != (B, Ho, Wo, Cout) or out_view.stride(3) != 1 or \
-                    out_view.stride(1) != Wo * out_view.stride(2) or out_view.stride(0) != Ho * out_view.stride(1):
-                raise ValueError("out_view must be a [B,Ho,Wo,Cout] channel slice of a contiguous NHWC buffer")
-            out, out_ld = out_view, out_view.stride(2)
-        else:
-            out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+        out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
         resh = None if res is None else _nhwc(res)
         # leaky + residual: `out` keeps leaky(conv) for the backward mask, `out2` = out + res
         out2 = torch.empty_like(out) if (leaky and res is not None) else None
         _igemm(xh, wp, out, B=B, Hi=Hi, Wi=Wi, Cin=Cin, Ho=Ho, Wo=Wo, Cout=Cout, kh=kh, kw=kw,
                stride=stride, pad=pad, transposed=transposed, bias=bias,
                epilogue=L.EPI_LEAKY if leaky else L.EPI_NONE, slope=slope, tap_mask=tap_mask,
-               res=resh, out2=out2, out_ld=out_ld)
+               res=resh, out2=out2)
         ctx.save_for_backward(xh, weight, out if leaky else None)
         ctx.cfg = (stride, pad, transposed, leaky, slope, tap_mask, bias is not None, res is not None)
         return _nchw_view(out2 if out2 is not None else out)
@@ -328,7 +298,7 @@ class _ConvFn(torch.autograd.Function):
         dx, dw, db = _conv_backward(xh, weight, g, stride, pad, transposed, tap_mask,
                                     ctx.needs_input_grad[0], ctx.needs_input_grad[1],
                                     has_bias and ctx.needs_input_grad[2])
-        return dx, dw, db, None, None, None, None, None, None, None, (gy if has_res else None), None
+        return dx, dw, db, None, None, None, None, None, None, None, (gy if has_res else None)
 
 
 def _conv_backward(xh, weight, g, stride, pad, transposed, tap_mask, need_dx, need_dw, need_db):
@@ -366,31 +336,8 @@ def _bias_grad(g, P, Cout):
     return _colsum(g, P, Cout)
 
 
-def conv2d(x, weight, bias, stride=1, padding=0, leaky=False, slope=0.01, tap_mask=0, residual=None, out=None):
-    """`out`: optional [B,Ho,Wo,Cout] channel slice of a wider contiguous NHWC buffer to write into (the kernel's
-    row pitch `out_ld`); the result is then a view of that buffer."""
-    return _ConvFn.apply(x, weight, bias, stride, padding, 0, False, leaky, slope, tap_mask, residual, out)
-
-
-class _JoinChannelsFn(torch.autograd.Function):
-    """`torch.cat([a, b], dim=1)` (Models.py:73) when a and b were WRITTEN as the two channel ranges of `buf`
-    (conv2d(..., out=slice)): the forward is a view, the backward hands each producer its slice of the gradient."""
-
-    @staticmethod
-    def forward(ctx, a, b, buf):
-        ca, cb = a.shape[1], b.shape[1]
-        if buf.shape[-1] != ca + cb or a.data_ptr() != buf.data_ptr() or b.data_ptr() != buf.data_ptr() + 4 * ca:
-            raise ValueError("join_channels: the operands are not the two channel ranges of the buffer")
-        ctx.ca = ca
-        return _nchw_view(buf)
-
-    @staticmethod
-    def backward(ctx, g):
-        return g[:, :ctx.ca], g[:, ctx.ca:], None
-
-
-def join_channels(a, b, buf):
-    return _JoinChannelsFn.apply(a, b, buf)
+def conv2d(x, weight, bias, stride=1, padding=0, leaky=False, slope=0.01, tap_mask=0, residual=None):
+    return _ConvFn.apply(x, weight, bias, stride, padding, 0, False, leaky, slope, tap_mask, residual)
 
 
 def pack_conv_weight(weight: torch.Tensor) -> torch.Tensor:
