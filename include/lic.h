@@ -10,9 +10,10 @@
  * Conventions
  *  - All pointers are DEVICE pointers to fp32 unless stated.  Activations are NHWC: element
  *    (b,h,w,c) of a tensor with row pitch `ld` (floats per pixel, ld >= C) lives at
- *    ((b*H + h)*W + w)*ld + c.  `ld` lets a producer write a channel range of a wider buffer and a
- *    consumer read one (strided views).  (The host layer still materialises the reference's
- *    torch.cat([phi, psi]), Models.py:73, as one 25 MB device copy per step: models.py.)
+ *    ((b*H + h)*W + w)*ld + c.  `ld` lets two producers write disjoint channel ranges of one
+ *    buffer: the reference's torch.cat([phi, psi]) (Models.py:73) is not materialised in the fp32
+ *    path -- the context conv and the hyper decoder's last conv write the two halves of one tensor
+ *    (models.py; the backward's two gradient slices are still made contiguous by a copy each).
  *  - The library never allocates, frees or synchronises; every launch goes to `stream`
  *    (a hipStream_t passed as void*), so every call is hipGraph-capturable.  Workspaces are
  *    caller-owned; sizes come from the *_workspace_bytes queries.

@@ -314,7 +314,7 @@ class ContextCodec:
         # CRC-32 of every image's latent symbols: a decoder whose tables differ from the encoder's by one count
         # decodes garbage silently; with the checksum it fails loudly instead
         y_crc = [zlib.crc32(np.ascontiguousarray(a).tobytes()) & 0xFFFFFFFF
-                 for a in y_sym.view(B, h * w * M).cpu().numpy().astype(np.int32)]
+                 for a in y_sym.reshape(B, h * w * M).cpu().numpy().astype(np.int32)]
         return {"strings": {"y": y_streams, "z": z_bytes, "y_crc32": y_crc}, "shape": (B, M, h, w),
                 "z_shape": tuple(z_in.shape),
                 "bpp_coded": coded, "bpp_est": est, "y_in": y_in, "z_in": z_in}

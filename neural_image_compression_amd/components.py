@@ -14,10 +14,12 @@ class _Stack(nn.Module):
     precision = "fp32"  # "bf16": bf16 activations between the layers (5x5 stacks and the hyper stacks)
     out_f32 = True      # bf16 mode: the stack's result in fp32 (latents, image) or bf16 (features for a bf16 consumer)
 
-    def forward(self, x):
+    def forward(self, x, out=None):
         if self.precision == "bf16":
+            if out is not None:
+                raise NotImplementedError
             return run_bf16(self.net, x, self.out_f32)
-        return run_fused(self.net, x)
+        return run_fused(self.net, x, out)
 
 
 class Encoder5x5(_Stack):

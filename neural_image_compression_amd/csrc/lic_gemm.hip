@@ -973,6 +973,24 @@ LIC_EXPORT int lic_igemm_fused_gdn_supported(int32_t Cin, int32_t Cout) {
   return (Cout == 64 || Cout == 128 || Cout == 192) && Cin > 0 && Cin % 4 == 0;
 }
 
+// K-split factor of a launch (1 = no split).  A function of per-image geometry only -- never of the batch
+// size or of the tile -- so an image's result does not depend on which batch it is computed in (bitwise
+// batch-split invariance: the split changes the summation order, the tile does not).
+static long igemm_geo_split(const lic_igemm_desc* d, int Npad, int max_chunks, int epi, bool fuse) {
+  const bool simple_epi = (epi == LIC_EPI_NONE || epi == LIC_EPI_LEAKY) && !d->res && !d->out2 && d->prologue < 2;
+  const long t_img = (((long)d->Ho * d->Wo + 63) / 64) * ((Npad + 63) / 64);
+  const char* env_split = d->force_split > 0 ? nullptr : getenv("LIC_IGEMM_FORCE_SPLIT");
+  if (!(simple_epi && !fuse && d->workspace && (t_img < 40 || env_split || d->force_split > 1) && d->force_split != 1 &&
+        (max_chunks >= 16 || d->force_split > 1)))
+    return 1;
+  long S = (40 + t_img - 1) / t_img;
+  if (S > max_chunks / 8) S = max_chunks / 8;  // at least 8 chunks per split
+  if (S > 32) S = 32;
+  if (env_split) S = atoi(env_split);  // tuning aid
+  if (d->force_split > 1) S = d->force_split < max_chunks ? d->force_split : max_chunks;
+  return S > 1 ? S : 1;
+}
+
 // fills the kernel parameter block; returns LIC_OK, or 1 when there is nothing to launch
 static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& TN, long& nwg,
                          int64_t& live_macs) {
@@ -1092,6 +1110,13 @@ static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& 
   int best = 5;
   long best_wg = -1;
   bool found = false;
+  // Small layers get their K loop split across workgroups (below).  The split factor depends on per-image
+  // geometry only -- never on the tile -- so it is known here, and a full-N tile may count its splits as
+  // workgroups: the 16x16 latent layers then take 64x192 tiles (activations gathered once per 192 columns)
+  // instead of 64x64 ones.
+  int max_chunks0 = 0;
+  for (int ph = 0; ph < p.nphase; ++ph) max_chunks0 = p.ntaps[ph] * p.cpt > max_chunks0 ? p.ntaps[ph] * p.cpt : max_chunks0;
+  const long S_geo = getenv("LIC_IGEMM_SPLIT_AWARE") ? igemm_geo_split(d, p.Npad, max_chunks0, epi, fuse) : 1;
   // first pass: shapes whose N tiling comes out full (branch-free MFMA block); second: any
   for (int pass = 0; pass < 2 && !found; ++pass)
     for (int c = 0; c < 6; ++c) {
@@ -1102,7 +1127,8 @@ static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& 
       if (bm == 128 && max_taps * p.cpt <= 16) continue;
       if (p.Npad < 64 * tn && tn > 1 && p.Npad <= 64 * (tn - 1)) continue;  // wider than the problem
       if (pass == 0 && p.Npad % (64 * tn) != 0) continue;
-      const long wgs = ((maxP + bm - 1) / bm) * ((p.Npad + 64 * tn - 1) / (64 * tn)) * p.nphase;
+      long wgs = ((maxP + bm - 1) / bm) * ((p.Npad + 64 * tn - 1) / (64 * tn)) * p.nphase;
+      if (pass == 0) wgs *= S_geo;
       if (wgs >= 512) {
         best = c;
         best_wg = wgs;
@@ -1164,18 +1190,8 @@ static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& 
   int max_chunks = 0;
   for (int ph = 0; ph < p.nphase; ++ph) max_chunks = p.ntaps[ph] * p.cpt > max_chunks ? p.ntaps[ph] * p.cpt : max_chunks;
   p.cps = max_chunks > 0 ? max_chunks : 1;
-  const bool simple_epi = (epi == LIC_EPI_NONE || epi == LIC_EPI_LEAKY) && !d->res && !d->out2 && d->prologue < 2;
-  // The split factor depends only on per-image geometry (never on the batch size), so an image's
-  // result does not depend on which batch it is computed in (bitwise batch-split invariance).
-  const long t_img = (((long)d->Ho * d->Wo + 63) / 64) * ((p.Npad + 63) / 64);
-  const char* env_split = d->force_split > 0 ? nullptr : getenv("LIC_IGEMM_FORCE_SPLIT");
-  if (simple_epi && !fuse && d->workspace && (t_img < 40 || env_split || d->force_split > 1) && d->force_split != 1 &&
-      (max_chunks >= 16 || d->force_split > 1)) {
-    long S = (40 + t_img - 1) / t_img;
-    if (S > max_chunks / 8) S = max_chunks / 8;  // at least 8 chunks per split
-    if (S > 32) S = 32;
-    if (env_split) S = atoi(env_split);  // tuning aid
-    if (d->force_split > 1) S = d->force_split < max_chunks ? d->force_split : max_chunks;
+  {
+    const long S = igemm_geo_split(d, p.Npad, max_chunks, epi, fuse);
     if (S > 1) {
       p.cps = (int)((max_chunks + S - 1) / S);
       p.ksplit = (max_chunks + p.cps - 1) / p.cps;

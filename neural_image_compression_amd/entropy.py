@@ -155,13 +155,13 @@ class MaskedConv2d(Conv2d):
                     live |= 1 << (r * kW + s)
         self._tap_mask = live
 
-    def forward(self, x: Tensor, bf16: bool = False) -> Tensor:
+    def forward(self, x: Tensor, bf16: bool = False, out=None) -> Tensor:
         if F_.prepared(self.weight, "masked") is None:  # else this step's lic_prep_run already masked it in place
             F_.mask_weight_(self.weight, self.mask)
         s, p = self.stride[0], self.padding[0]
         if bf16:  # bf16 features out (they feed the bf16 entropy-parameter MLP)
             return FB_.conv2d_bf16(x, self.weight, self.bias, s, p, False, False, 0.01, self._tap_mask)
-        return F_.conv2d(x, self.weight, self.bias, s, p, False, 0.01, self._tap_mask)
+        return F_.conv2d(x, self.weight, self.bias, s, p, False, 0.01, self._tap_mask, None, out)
 
 
 class ContextModel(nn.Module):
@@ -172,8 +172,8 @@ class ContextModel(nn.Module):
         self.masked = MaskedConv2d("A", in_channels=latent_channels, out_channels=2 * latent_channels,
                                    kernel_size=5, stride=1, padding=2)
 
-    def forward(self, x):
-        return self.masked(x, bf16=self.precision == "bf16")
+    def forward(self, x, out=None):
+        return self.masked(x, bf16=self.precision == "bf16", out=out)
 
 
 class EntropyParameters(nn.Module):

@@ -266,7 +266,7 @@ class _ConvFn(torch.autograd.Function):
     ParametersModels.py:22-34; ContextModels.py:19-20."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, out_pad, transposed, leaky, slope, tap_mask, res):
+    def forward(ctx, x, weight, bias, stride, pad, out_pad, transposed, leaky, slope, tap_mask, res, out_view=None):
         _require_cuda(x, weight, bias, res)
         xh = _nhwc(x)
         B, Hi, Wi, Cin = xh.shape
@@ -274,14 +274,22 @@ class _ConvFn(torch.autograd.Function):
         Cout = weight.shape[1] if transposed else weight.shape[0]
         Ho, Wo = conv_out_size(Hi, Wi, kh, stride, pad, transposed, out_pad)
         wp = _pack_conv_weight(weight, transposed, for_dgrad=False)
-        out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+        out_ld = None
+        if out_view is not None:
+            # the caller's channel range of a wider NHWC buffer (two producers fill one tensor: no torch.cat)
+            if leaky or res is not None or tuple(out_view.shape) != (B, Ho, Wo, Cout) or out_view.stride(3) != 1 or \
+                    out_view.stride(1) != Wo * out_view.stride(2) or out_view.stride(0) != Ho * out_view.stride(1):
+                raise ValueError("out_view must be a [B,Ho,Wo,Cout] channel slice of a contiguous NHWC buffer")
+            out, out_ld = out_view, out_view.stride(2)
+        else:
+            out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
         resh = None if res is None else _nhwc(res)
         # leaky + residual: `out` keeps leaky(conv) for the backward mask, `out2` = out + res
         out2 = torch.empty_like(out) if (leaky and res is not None) else None
         _igemm(xh, wp, out, B=B, Hi=Hi, Wi=Wi, Cin=Cin, Ho=Ho, Wo=Wo, Cout=Cout, kh=kh, kw=kw,
                stride=stride, pad=pad, transposed=transposed, bias=bias,
                epilogue=L.EPI_LEAKY if leaky else L.EPI_NONE, slope=slope, tap_mask=tap_mask,
-               res=resh, out2=out2)
+               res=resh, out2=out2, out_ld=out_ld)
         ctx.save_for_backward(xh, weight, out if leaky else None)
         ctx.cfg = (stride, pad, transposed, leaky, slope, tap_mask, bias is not None, res is not None)
         return _nchw_view(out2 if out2 is not None else out)
@@ -298,7 +306,7 @@ class _ConvFn(torch.autograd.Function):
         dx, dw, db = _conv_backward(xh, weight, g, stride, pad, transposed, tap_mask,
                                     ctx.needs_input_grad[0], ctx.needs_input_grad[1],
                                     has_bias and ctx.needs_input_grad[2])
-        return dx, dw, db, None, None, None, None, None, None, None, (gy if has_res else None)
+        return dx, dw, db, None, None, None, None, None, None, None, (gy if has_res else None), None
 
 
 def _conv_backward(xh, weight, g, stride, pad, transposed, tap_mask, need_dx, need_dw, need_db):
@@ -336,8 +344,31 @@ def _bias_grad(g, P, Cout):
     return _colsum(g, P, Cout)
 
 
-def conv2d(x, weight, bias, stride=1, padding=0, leaky=False, slope=0.01, tap_mask=0, residual=None):
-    return _ConvFn.apply(x, weight, bias, stride, padding, 0, False, leaky, slope, tap_mask, residual)
+def conv2d(x, weight, bias, stride=1, padding=0, leaky=False, slope=0.01, tap_mask=0, residual=None, out=None):
+    """`out`: optional [B,Ho,Wo,Cout] channel slice of a wider contiguous NHWC buffer to write into (the kernel's
+    row pitch `out_ld`); the result is then a view of that buffer."""
+    return _ConvFn.apply(x, weight, bias, stride, padding, 0, False, leaky, slope, tap_mask, residual, out)
+
+
+class _JoinChannelsFn(torch.autograd.Function):
+    """`torch.cat([a, b], dim=1)` (Models.py:73) when a and b were WRITTEN as the two channel ranges of `buf`
+    (conv2d(..., out=slice)): the forward is a view, the backward hands each producer its slice of the gradient."""
+
+    @staticmethod
+    def forward(ctx, a, b, buf):
+        ca, cb = a.shape[1], b.shape[1]
+        if buf.shape[-1] != ca + cb or a.data_ptr() != buf.data_ptr() or b.data_ptr() != buf.data_ptr() + 4 * ca:
+            raise ValueError("join_channels: the operands are not the two channel ranges of the buffer")
+        ctx.ca = ca
+        return _nchw_view(buf)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[:, :ctx.ca], g[:, ctx.ca:], None
+
+
+def join_channels(a, b, buf):
+    return _JoinChannelsFn.apply(a, b, buf)
 
 
 def pack_conv_weight(weight: torch.Tensor) -> torch.Tensor:

@@ -25,10 +25,12 @@ def _pair(v):
 
 class Conv2d(nn.Conv2d):
     def forward(self, x: Tensor, leaky: bool = False, slope: float = 0.01, residual=None, bf16: bool = False,
-                out_f32: bool = False) -> Tensor:
+                out_f32: bool = False, out=None) -> Tensor:
         if self.groups != 1 or _pair(self.dilation) != 1:
             raise NotImplementedError("groups/dilation are not used by the reference models")
         s, p = _pair(self.stride), _pair(self.padding)
+        if out is not None and (bf16 or self.in_channels < 4):
+            raise NotImplementedError("`out` slices are for the fp32 implicit-GEMM path")
         if bf16:  # bf16-storage path (BASELINE config 3): conv + bias (+ fused LeakyReLU)
             if residual is not None:
                 raise NotImplementedError("bf16 mode covers the 5x5 conv/GDN stacks and the latent-side layers")
@@ -40,7 +42,7 @@ class Conv2d(nn.Conv2d):
         if self.in_channels < 4:  # RGB stem: im2col + dense MFMA GEMM
             y = F_.image_conv2d(x, self.weight, self.bias, s, p, leaky, slope)
             return y if residual is None else y + residual
-        return F_.conv2d(x, self.weight, self.bias, s, p, leaky, slope, 0, residual)
+        return F_.conv2d(x, self.weight, self.bias, s, p, leaky, slope, 0, residual, out)
 
 
 class ConvTranspose2d(nn.ConvTranspose2d):
@@ -112,10 +114,12 @@ def _conv_gdn(conv, g: "GDN", x: Tensor) -> Tensor:
                        output_padding=_pair(conv.output_padding) if tr else 0)
 
 
-def run_fused(seq: nn.Sequential, x: Tensor) -> Tensor:
+def run_fused(seq: nn.Sequential, x: Tensor, out=None) -> Tensor:
     """Run an nn.Sequential of our layers, folding Conv -> LeakyReLU and Conv -> GDN pairs into one
-    kernel each."""
+    kernel each.  `out`: NHWC channel slice the LAST layer (a plain Conv2d) writes its result into."""
     mods = list(seq)
+    if out is not None and not (isinstance(mods[-1], Conv2d) and mods[-1].in_channels >= 4):
+        raise NotImplementedError("`out` needs a plain Conv2d as the last layer")
     i = 0
     while i < len(mods):
         m = mods[i]
@@ -134,6 +138,9 @@ def run_fused(seq: nn.Sequential, x: Tensor) -> Tensor:
         elif fusable and isinstance(nxt, LeakyReLU):
             x = m(x, leaky=True, slope=nxt.negative_slope)
             i += 2
+        elif out is not None and i == len(mods) - 1:
+            x = m(x, out=out)
+            i += 1
         else:
             x = m(x)
             i += 1

@@ -83,9 +83,20 @@ class _HyperpriorContextModel(nn.Module):
             _fork(y_in)
         z = self.hyper_encoder(y)
         z_in = F_.quantize(z, uz, True) if training else F_.quantize(z, None, False)
-        psi = self.hyper_decoder(z_in)
-        phi = self.context_model(y_in)
-        combined = torch.cat([phi, psi], dim=1)  # layout copy only (phi first)
+        if x.is_cuda and self.context_model.precision == "fp32" and self.hyper_decoder.precision == "fp32":
+            # Models.py:73 `torch.cat([phi, psi], dim=1)` without the copy: the context conv and the hyper
+            # decoder's last conv write the two channel ranges of one NHWC buffer (phi first)
+            Bn, _, hh, ww = y_in.shape
+            c_phi = self.context_model.masked.out_channels
+            c_psi = self.hyper_decoder.net[-1].out_channels
+            comb = torch.empty((Bn, hh, ww, c_phi + c_psi), device=x.device, dtype=torch.float32)
+            psi = self.hyper_decoder(z_in, out=comb[..., c_phi:])
+            phi = self.context_model(y_in, out=comb[..., :c_phi])
+            combined = F_.join_channels(phi, psi, comb)
+        else:
+            psi = self.hyper_decoder(z_in)
+            phi = self.context_model(y_in)
+            combined = torch.cat([phi, psi], dim=1)  # (bf16 features: a 6 MB layout copy, phi first)
         act = self.entropy_parameters.packed(combined)
         if self.K == 1:
             mu, sigma = self.entropy_parameters.split(act)

@@ -112,3 +112,14 @@ def test_host_codec_library_exports_its_header():
 def test_check_raises_with_status_name(lib):
     with pytest.raises(lib.LicError, match="LIC_ERR_INVALID"):
         lib.check(-1, "probe")
+
+
+def test_descriptor_structs_have_the_c_layout(lib, tmp_path):
+    """the ctypes mirrors of lic_igemm_desc / lic_wgrad_desc / lic_prep_job are as large as the C structs"""
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include "lic.h"\nint main(void){printf("%zu %zu %zu\\n", sizeof(lic_igemm_desc), '
+                   'sizeof(lic_wgrad_desc), sizeof(lic_prep_job));return 0;}\n')
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    c_sizes = [int(v) for v in subprocess.check_output([str(exe)], text=True).split()]
+    assert c_sizes == [ctypes.sizeof(lib.IgemmDesc), ctypes.sizeof(lib.WgradDesc), ctypes.sizeof(lib.PrepJob)]
