@@ -262,7 +262,7 @@ def main():
             ach = flops / secs / 1e12
             # HBM bytes per launch from the committed PMC passes (separate --pmc FETCH_SIZE / WRITE_SIZE
             # runs of this same command, gfx950 x2 read correction applied; see the file's "_how")
-            traffic = None
+            traffic = traffic_src = None
             try:
                 import glob
                 newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
@@ -270,12 +270,16 @@ def main():
                 for kname, v in pmc.items():
                     if dom in kname and (H, W, B, M, K) == (256, 256, 32, 192, 1):
                         traffic = v["traffic_bytes_per_launch"]
+                        traffic_src = os.path.relpath(newest, ROOT)
             except Exception:
                 traffic = None
             peak = BF16_MFMA_PEAK_TF if "bf16" in dom else FP32_MFMA_PEAK_TF
             line["roofline"] = {
                 "kernel": dom, "bound": "mfma", "achieved": round(ach, 2), "peak": peak,
                 "unit": "TFLOP/s", "frac": round(ach / peak, 4), "traffic": traffic,
+                # (PMC counters need rocprofv3 around the process: `traffic` is the figure of the newest committed
+                # --pmc passes of this same command, tools/refresh_profiles.sh; every other number here is live)
+                "traffic_source": traffic_src,
                 "launches": n, "avg_launch_ms": round(secs / n * 1e3, 4),
                 "alg_gflop_per_launch": round(flops / n / 1e9, 3),
                 "hbm_frac_of_alg_bytes": round(abytes / secs / 1e9 / HBM_PEAK_GBS, 4),

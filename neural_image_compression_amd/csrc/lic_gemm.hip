@@ -1116,7 +1116,7 @@ static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& 
   // instead of 64x64 ones.
   int max_chunks0 = 0;
   for (int ph = 0; ph < p.nphase; ++ph) max_chunks0 = p.ntaps[ph] * p.cpt > max_chunks0 ? p.ntaps[ph] * p.cpt : max_chunks0;
-  const long S_geo = getenv("LIC_IGEMM_SPLIT_AWARE") ? igemm_geo_split(d, p.Npad, max_chunks0, epi, fuse) : 1;
+  const long S_geo = (getenv("LIC_IGEMM_SPLIT_AWARE") && getenv("LIC_IGEMM_SPLIT_AWARE")[0] == '0') ? 1 : igemm_geo_split(d, p.Npad, max_chunks0, epi, fuse);
   // first pass: shapes whose N tiling comes out full (branch-free MFMA block); second: any
   for (int pass = 0; pass < 2 && !found; ++pass)
     for (int c = 0; c < 6; ++c) {
