@@ -71,9 +71,14 @@ class _HyperpriorContextModel(nn.Module):
             if noise is None:
                 # the reference draws rand_like(z) then rand_like(y) (Models.py:57-58); z's shape is known
                 # before z is, and drawing both here lets the decoder branch start right after the encoder
-                zshape = (y.shape[0], y.shape[1], (y.shape[2] + 3) // 4, (y.shape[3] + 3) // 4)
-                uz = torch.rand(zshape, device=y.device, dtype=y.dtype)
-                uy = torch.rand_like(y)
+                # (one generator launch for both; each tensor is laid out NHWC like the latent it perturbs, so the
+                # quantisation kernel reads it in place -- an NCHW u_z cost a layout-copy launch per step)
+                Bn, Mc, hy, wy = y.shape
+                hz, wz = (hy + 3) // 4, (wy + 3) // 4
+                nz, ny = Bn * hz * wz * Mc, Bn * hy * wy * Mc
+                u = torch.rand(nz + ny, device=y.device, dtype=y.dtype)
+                uz = u[:nz].view(Bn, hz, wz, Mc).permute(0, 3, 1, 2)
+                uy = u[nz:].view(Bn, hy, wy, Mc).permute(0, 3, 1, 2)
             else:
                 uz, uy = noise
             y_in = F_.quantize(y, uy, True)

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
-"""How fast is a gloo all-reduce of a gradient-sized buffer between two ranks sharing one GPU?
-(CUDA tensor through gloo's own staging vs an explicit pinned host copy.)  Launch with torch.distributed.run."""
+"""How long does a gloo all-reduce take between two ranks that SHARE one GPU, as a function of the buffer size
+and of whether the GPU is busy with the ranks' own kernels?  (The data-parallel rehearsal on a one-GPU box;
+explains why an extra, latency-sized tail bucket made that rehearsal 10-100x slower: DESIGN.md section 5.)
+Launch:  python -m torch.distributed.run --nproc-per-node 2 --master-addr 127.0.0.1 tools/gloo_probe.py"""
 import os
 import time
 
@@ -11,22 +13,27 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 dist.init_process_group("gloo")
 r = dist.get_rank()
 torch.cuda.set_device(0)
-x = torch.randn(4 * 1024 * 1024, device="cuda")  # 16 MB
-h = torch.empty(x.shape, dtype=x.dtype, pin_memory=True)
-for name in ("cuda tensor", "pinned host copy", "cuda tensor", "pinned host copy"):
+busy_a = torch.randn(8192, 8192, device="cuda")
+
+
+def timed(n_floats, busy, reps=4):
+    x = torch.randn(n_floats, device="cuda")
+    dist.all_reduce(x)
+    torch.cuda.synchronize()
     dist.barrier()
-    torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(4):
-        if name == "cuda tensor":
-            dist.all_reduce(x)
-        else:
-            h.copy_(x, non_blocking=True)
-            torch.cuda.current_stream().synchronize()
-            dist.all_reduce(h)
-            x.copy_(h, non_blocking=True)
+    for _ in range(reps):
+        if busy:                       # ~20 ms of queued GPU work in front of the collective, in BOTH ranks
+            for _ in range(4):
+                busy_a @ busy_a
+        dist.all_reduce(x)
     torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    if r == 0:
-        print(f"{name:18s}: {dt / 4 * 1e3:8.1f} ms per 16 MB all-reduce", flush=True)
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+for busy in (False, True):
+    for n in (256, 16 * 1024, 256 * 1024, 4 * 1024 * 1024):
+        ms = timed(n, busy)
+        if r == 0:
+            print(f"gloo all-reduce of {n * 4 / 1024:9.1f} KiB, GPU {'busy' if busy else 'idle'}: {ms:8.2f} ms", flush=True)
 dist.destroy_process_group()
