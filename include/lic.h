@@ -66,7 +66,8 @@ enum lic_epilogue {
  *   transposed == 0:  out[b,oh,ow,:] = sum_{r,s} in[b, oh*stride-pad+r, ow*stride-pad+s, :] . W[r,s]
  *   transposed == 1:  out[b,oy,ox,:] = sum_{r,s : (oy+pad-r) % stride == 0 ...}
  *                                       in[b,(oy+pad-r)/stride,(ox+pad-s)/stride,:] . W[r,s]
- *   W is the packed weight produced by lic_pack_weight: [kh*kw][ceil(Cin/16)][ceil32(Cout)/32][2][64][4]
+ *   W is the packed weight produced by lic_pack_weight: [kh*kw][ceil(Cin/16)][Npad/32][2][64][4], Npad = Cout
+ *   rounded up to 64 (32 when Cout <= 32)
  *   (an opaque MFMA-operand order: element (k, n) of a chunk sits at lane (n%32) + 32*((k%16)/8),
  *   load q = (k%8)/4, float k%4)
  * Replaces: nn.Conv2d / nn.ConvTranspose2d forward and their input gradients
@@ -107,7 +108,7 @@ typedef struct lic_igemm_desc {
    * workloads dispatch in front of the oracle at sizes the oracle finishes in seconds, and the entropy
    * coder pins one variant so that encoder and decoder build bit-identical tables whatever their batch.
    *   force_bm in {64,128}, force_tn in {1,2,3} (both or neither; needs float4-aligned operands and
-   *   ceil32(Cout) % (64*force_tn) == 0, else LIC_ERR_UNSUPPORTED); force_split >= 1: K splits
+   *   Npad % (64*force_tn) == 0, else LIC_ERR_UNSUPPORTED); force_split >= 1: K splits
    *   (1 = never split; needs `workspace`). */
   int32_t force_bm, force_tn, force_split, reserved0;
 } lic_igemm_desc;

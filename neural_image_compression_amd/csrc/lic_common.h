@@ -23,6 +23,12 @@ static inline int lic_check_launch() {
 
 static inline int64_t cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// Column pitch of the packed fp32 MFMA weight operand (lic_pack_weight / lic_prep_run / lic_igemm must agree):
+// whole 64-column wave pairs, so that every layer wider than one 32-column tile has a full-N tiling and runs
+// the branch-free LDS-DMA variant -- the 288-wide hyper-decoder layers (Components.py:101-103) and the 80-wide
+// column matrix of the RGB head ran the ragged register-staged variant at half its speed with ceil32.
+static inline int lic_npad_f32(int N) { return N <= 32 ? 32 : ((N + 63) / 64) * 64; }
+
 // grid for grid-stride elementwise kernels: enough blocks to fill 256 CUs x 8, no more
 static inline int ew_grid(int64_t n, int per_block) {
   int64_t g = cdiv64(n, per_block);

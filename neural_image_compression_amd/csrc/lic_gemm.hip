@@ -783,7 +783,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
 
 static bool aligned16(const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
-// ---- weight packing: dst[tap][chunk][n/32][q][lane][4], zero padded to Npad = ceil32(N), K to 16.
+// ---- weight packing: dst[tap][chunk][n/32][q][lane][4], zero padded to Npad = lic_npad_f32(N), K to 16.
 // Lane (col li = lane&31, K-half lh = lane>>5) of a wave owns k = lh*8 + q*4 + e of column
 // n = 32*tile + li, so each of its two B loads per 32-column tile reads lane*16 B of one
 // contiguous 1 KiB block (fully coalesced, whole cache lines).
@@ -889,12 +889,12 @@ __global__ __launch_bounds__(256) void pack_weight_tiled_kernel(const float* src
 }
 LIC_EXPORT int64_t lic_packed_weight_floats(int32_t taps, int32_t K, int32_t N) {
   if (taps <= 0 || K <= 0 || N <= 0) return 0;
-  return (int64_t)taps * ((K + IG_BK - 1) / IG_BK) * (((N + 31) / 32) * 32) * IG_BK;
+  return (int64_t)taps * ((K + IG_BK - 1) / IG_BK) * lic_npad_f32(N) * IG_BK;
 }
 LIC_EXPORT int lic_pack_weight(const float* src, float* dst, int32_t taps, int32_t K, int32_t N,
                                int64_t s_tap, int64_t s_k, int64_t s_n, lic_stream_t stream) {
   if (!src || !dst || taps <= 0 || K <= 0 || N <= 0) return LIC_ERR_INVALID;
-  const int cpt = (K + IG_BK - 1) / IG_BK, Npad = ((N + 31) / 32) * 32;
+  const int cpt = (K + IG_BK - 1) / IG_BK, Npad = lic_npad_f32(N);
   const long total = (long)taps * cpt * Npad * IG_BK;
   const int ntile = Npad / 32;
   const size_t lds = (size_t)taps * IG_BK * (PK_NS + 1) * sizeof(float);
@@ -1054,7 +1054,7 @@ static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& 
   p.slope = d->slope;
   p.vec = (d->Cin % 4 == 0) && (d->in_ld % 4 == 0) && aligned16(d->in);
   p.cpt = (d->Cin + IG_BK - 1) / IG_BK;
-  p.Npad = ((d->Cout + 31) / 32) * 32;
+  p.Npad = lic_npad_f32(d->Cout);
   {
     auto okp = [](const void* q, int64_t ld) { return q == nullptr || (aligned16(q) && ld % 4 == 0); };
     p.vec_out = (d->Cout % 4 == 0) && okp(d->out, d->out_ld) && okp(d->out2, d->out2_ld) &&

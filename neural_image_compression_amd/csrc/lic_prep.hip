@@ -223,7 +223,7 @@ LIC_EXPORT int64_t lic_prep_plan(lic_prep_job* jobs, int32_t njobs) {
       const bool h = j.kind == LIC_PREP_PACK_BF16;
       const int bk = h ? PP_HBK : PP_BK;
       j.cpt = (j.K + bk - 1) / bk;
-      j.npad = h ? ((j.N + 63) / 64) * 64 : ((j.N + 31) / 32) * 32;
+      j.npad = h ? ((j.N + 63) / 64) * 64 : lic_npad_f32(j.N);
       j.total = (long)j.taps * j.cpt * j.npad * bk;
       const long s_k = j.s_kq, s_n = j.s_nq;
       const bool plain = j.kdiv == 0 && j.ndiv == 0 && j.transform == 0 && j.mask == nullptr;

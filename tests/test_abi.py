@@ -55,7 +55,7 @@ def test_argument_validation_without_gpu(lib):
     assert L.lic_permute3(None, None, 1, 1, 1, 1, 1, 1, 1, 1, 1, None) == -1
     assert L.lic_pack_weight(None, None, 1, 1, 1, 1, 1, 1, None) == -1
     assert L.lic_packed_weight_floats(25, 192, 192) == 25 * 12 * 192 * 16
-    assert L.lic_packed_weight_floats(1, 80, 75) == 5 * 96 * 16
+    assert L.lic_packed_weight_floats(1, 80, 75) == 5 * 128 * 16   # columns padded to whole 64-wide wave pairs
     assert L.lic_quantize(None, None, None, 4, 1, None) == -1
     assert L.lic_gmm_likelihood_fwd(None, None, None, None, 1, 1, 1, 1e-9, None) == -1
     assert L.lic_factorized_fwd(None, None, None, None, 1, 1, 1e-9, None) == -1
