@@ -505,7 +505,8 @@ def test_model_vs_oracle(env, kind, M, K, B, H, W):
 def _pack_layout_ref(w, taps, K, N, s_tap, s_k, s_n):
     """numpy restatement of include/lic.h's fp32 packed layout [tap][K/16][Npad/32][2][64][4]"""
     flat = w.reshape(-1)
-    cpt, ntile = (K + 15) // 16, (N + 31) // 32
+    npad = 32 if N <= 32 else (N + 63) // 64 * 64     # whole 64-column wave pairs (lic_common.h lic_npad_f32)
+    cpt, ntile = (K + 15) // 16, npad // 32
     out = np.zeros((taps, cpt, ntile, 2, 64, 4), np.float32)
     for tap in range(taps):
         for k in range(K):
