@@ -323,8 +323,8 @@ def test_real_5x5_layer_pair_vs_torch_cpu(env, B, H):
 # ---------------------------------------------------------------------------------------------
 # 2b. whole configurations at FULL size against oracle/torch_ref.py
 # ---------------------------------------------------------------------------------------------
-def _full_step(nic, dev, M, K, B, H, W, seed, precision="fp32", lam=0.01):
-    model = nic.JointAutoregressiveHierarchical(M, K)
+def _full_step(nic, dev, M, K, B, H, W, seed, precision="fp32", lam=0.01, cls=None):
+    model = (cls or nic.JointAutoregressiveHierarchical)(M, K)
     ks = [(k, tuple(v.shape)) for k, v in model.state_dict().items()]
     st = R.make_state(ks, seed)
     model.load_state_dict({k: torch.from_numpy(v) for k, v in st.items()})
@@ -378,6 +378,19 @@ def test_full_size_config_step_vs_torch_cpu_path(env, name):
     with traced(F_):
         model, st, x, noise, out, res = _full_step(nic, dev, M, K, B, H, W, 300 + M + K)
         t_out, t_loss, t_grads = TR.step(st, x, M, K, "5x5", noise, 0.01)
+        _compare_fp32(model, out, res, t_out, t_loss, t_grads)
+
+
+def test_hmr_full_capacity_step_vs_torch_cpu_path(env):
+    """SURVEY 8(a) row a5 at FULL capacity: HierarchicalMixtureResidual(192, K=3) -- the 3x3 residual stacks
+    (Components.py:20-32,49-62,77-91,107-122; Layers.py:18-119) -- 4x3x256x256, forward + rd_loss + backward
+    against the torch-CPU restatement, same tolerances as the 5x5 model."""
+    nic, F_, O, dev = env
+    from oracle import torch_ref as TR
+    M, K, B = 192, 3, 4
+    with traced(F_):
+        model, st, x, noise, out, res = _full_step(nic, dev, M, K, B, 256, 256, 610, cls=nic.HierarchicalMixtureResidual)
+        t_out, t_loss, t_grads = TR.step(st, x, M, K, "3x3", noise, 0.01)
         _compare_fp32(model, out, res, t_out, t_loss, t_grads)
 
 
