@@ -185,7 +185,9 @@ def main():
     if bf16:
         model.set_precision("bf16")
     broadcast_parameters(model)
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    # torch.optim.Adam's arithmetic and state dict, one launch per step (optim.FusedAdam -> lic_adam_run);
+    # LIC_TORCH_ADAM=1 runs torch's own nine multi-tensor launches instead (A/B)
+    opt = (torch.optim.Adam if os.environ.get("LIC_TORCH_ADAM") == "1" else nic.FusedAdam)(model.parameters(), lr=1e-4)
     reducer = GradientAllReducer(model.parameters(), overlap=os.environ.get("LIC_REDUCER_NO_OVERLAP") != "1",
                                  force=force_red, stream_groups=[list(model.decoder.parameters())],
                                  group_streams=[model.side_stream()] if model.overlap_branches else None) \

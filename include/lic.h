@@ -393,6 +393,28 @@ typedef struct lic_prep_job {
 int64_t lic_prep_plan(lic_prep_job* jobs, int32_t njobs);
 int lic_prep_run(const lic_prep_job* jobs_device, int32_t njobs, int64_t total_blocks, lic_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * lic_adam -- optimizer.step() (Trainer.py:86; the reference trains with torch.optim.Adam, Main.ipynb) for every
+ *   parameter of a model in ONE launch: g' = g + weight_decay*p; m += (1-beta1)(g'-m); v = beta2 v + (1-beta2) g'^2;
+ *   p -= (lr / bias_correction1) * m / (sqrt(v)/sqrt(bias_correction2) + eps)   -- torch's non-amsgrad arithmetic,
+ *   bias_correction{1,2} = 1 - beta{1,2}^step computed by the caller.  Jobs: fill p / m / v / n on the host,
+ *   lic_adam_plan (fills block0 / nblocks, returns the grid size), keep a device copy of the array; per step
+ *   lic_adam_run with `grads_host`, a HOST array of the njobs (<= 448) gradient device pointers in job order --
+ *   gradients are fresh allocations every step, so their addresses travel as kernel arguments.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct lic_adam_job {
+  float* p;       /* parameter, updated in place */
+  const float* g; /* unused (gradient pointers are passed to lic_adam_run) */
+  float* m;       /* exp_avg */
+  float* v;       /* exp_avg_sq */
+  int64_t n;      /* elements */
+  int32_t block0, nblocks; /* derived by lic_adam_plan */
+} lic_adam_job;
+int64_t lic_adam_plan(lic_adam_job* jobs, int32_t njobs);
+int lic_adam_run(const lic_adam_job* jobs_device, int32_t njobs, int64_t total_blocks, const float* const* grads_host,
+                 float lr, float beta1, float beta2, float eps, float weight_decay, float bias_correction1,
+                 float bias_correction2, lic_stream_t stream);
+
 int lic_version(void);        /* LIC_ABI_VERSION */
 int lic_last_hip_error(void); /* hipError_t of the most recent failed launch on this thread */
 const char* lic_arch(void);   /* "gfx950" */

@@ -11,6 +11,7 @@ _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 from .models import JointAutoregressiveHierarchical, HierarchicalMixtureResidual  # noqa: F401
 from .loss import rd_loss  # noqa: F401
+from .optim import FusedAdam  # noqa: F401
 from . import _lib  # noqa: F401
 
-__all__ = ["JointAutoregressiveHierarchical", "HierarchicalMixtureResidual", "rd_loss"]
+__all__ = ["JointAutoregressiveHierarchical", "HierarchicalMixtureResidual", "rd_loss", "FusedAdam"]

@@ -55,6 +55,10 @@ class PrepJob(C.Structure):
                 ("total", _i64)]
 
 
+class AdamJob(C.Structure):
+    _fields_ = [("p", _vp), ("g", _vp), ("m", _vp), ("v", _vp), ("n", _i64), ("block0", _i32), ("nblocks", _i32)]
+
+
 # name -> (restype, argtypes); every symbol declared in include/lic.h
 SIGNATURES = {
     "lic_igemm": (C.c_int, [C.POINTER(IgemmDesc), _vp]),
@@ -118,6 +122,8 @@ SIGNATURES = {
     "lic_tensor_stats": (C.c_int, [_vp, _i64, _i32, _f32, _f32, _vp, _vp, _vp, _sz, _vp]),
     "lic_prep_plan": (_i64, [C.POINTER(PrepJob), _i32]),
     "lic_prep_run": (C.c_int, [_vp, _i32, _i64, _vp]),
+    "lic_adam_plan": (_i64, [C.POINTER(AdamJob), _i32]),
+    "lic_adam_run": (C.c_int, [_vp, _i32, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
     "lic_version": (C.c_int, []),
     "lic_last_hip_error": (C.c_int, []),
     "lic_arch": (C.c_char_p, []),

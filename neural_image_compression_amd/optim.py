@@ -1,0 +1,84 @@
+"""`FusedAdam`: torch.optim.Adam whose `step()` is ONE kernel launch (`lic_adam_run`, include/lic.h) over every
+parameter instead of nine multi-tensor launches.
+
+A subclass of torch.optim.Adam: same constructor, same `state_dict()` (`step`, `exp_avg`, `exp_avg_sq` per
+parameter, created by torch's own `_init_group`), so checkpoints move freely between the two -- the reference's
+`Trainer` takes whatever optimizer it is given (Trainer.py:11-16) and the notebook builds `torch.optim.Adam`
+(Main.ipynb).  The arithmetic is torch's non-amsgrad Adam with L2 weight decay, bias corrections computed on
+the host from the step count (torch's default, non-capturable path); anything else -- amsgrad, maximize,
+capturable / differentiable, non-fp32 or CPU parameters, parameters without gradients, step counts that differ
+between parameters -- falls through to torch's implementation for that call.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from . import functional as F_
+
+
+class FusedAdam(torch.optim.Adam):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, **kw):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, **kw)
+        self._tables = {}   # group index -> (key, device job table, njobs, blocks, ctypes array of gradient pointers)
+        self.fused_steps = 0
+
+    def _eligible(self, group, params, grads):
+        if group["amsgrad"] or group.get("maximize") or group.get("capturable") or group.get("differentiable"):
+            return False
+        if isinstance(group["lr"], torch.Tensor) or not params:
+            return False
+        dev = params[0].device
+        for p, g in zip(params, grads):
+            if p.device != dev or not p.is_cuda or p.dtype != torch.float32 or g.dtype != torch.float32 or \
+                    g.is_sparse or not p.is_contiguous() or not g.is_contiguous():
+                return False
+        return dev.index == torch.cuda.current_device()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():
+                loss = closure()
+        plans = []
+        for gi, group in enumerate(self.param_groups):
+            params, grads, exp_avgs, exp_avg_sqs, max_sqs, steps = [], [], [], [], [], []
+            self._init_group(group, params, grads, exp_avgs, exp_avg_sqs, max_sqs, steps)
+            if len(params) != len([p for p in group["params"]]) or not self._eligible(group, params, grads) or \
+                    not all(m.is_contiguous() and v.is_contiguous() for m, v in zip(exp_avgs, exp_avg_sqs)) or \
+                    len({float(s) for s in steps}) != 1:
+                return self._fallback(loss)
+            plans.append((gi, group, params, grads, exp_avgs, exp_avg_sqs, steps))
+        lib = L.load()
+        for gi, group, params, grads, exp_avgs, exp_avg_sqs, steps in plans:
+            key = tuple((p.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()) for p, m, v in zip(params, exp_avgs, exp_avg_sqs))
+            tab = self._tables.get(gi)
+            if tab is None or tab[0] != key:
+                arr = (L.AdamJob * len(params))()
+                for j, (p, m, v) in zip(arr, zip(params, exp_avgs, exp_avg_sqs)):
+                    j.p, j.m, j.v, j.n = p.data_ptr(), m.data_ptr(), v.data_ptr(), p.numel()
+                blocks = lib.lic_adam_plan(arr, len(params))
+                if blocks <= 0:
+                    raise L.LicError(f"lic_adam_plan failed: {blocks}")
+                dev_tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(params[0].device)
+                tab = self._tables[gi] = (key, dev_tab, len(params), int(blocks), (C.c_void_p * len(params))())
+            _, dev_tab, njobs, blocks, gptrs = tab
+            for i, g in enumerate(grads):       # gradients are fresh tensors every step: their addresses go along
+                gptrs[i] = g.data_ptr()         # as kernel arguments (copied at launch)
+            for s in steps:
+                s += 1
+            t = float(steps[0])
+            beta1, beta2 = group["betas"]
+            L.check(lib.lic_adam_run(C.c_void_p(dev_tab.data_ptr()), njobs, blocks, gptrs, float(group["lr"]), float(beta1),
+                                     float(beta2), float(group["eps"]), float(group["weight_decay"]),
+                                     1.0 - beta1 ** t, 1.0 - beta2 ** t, F_._stream()), "lic_adam_run")
+        self.fused_steps += 1
+        return loss
+
+    def _fallback(self, loss):
+        """torch's own update for this call (state was initialised by the same `_init_group`)"""
+        super().step()
+        return loss
