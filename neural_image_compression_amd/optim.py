@@ -75,6 +75,9 @@ class FusedAdam(torch.optim.Adam):
             L.check(lib.lic_adam_run(C.c_void_p(dev_tab.data_ptr()), njobs, blocks, gptrs, float(group["lr"]), float(beta1),
                                      float(beta2), float(group["eps"]), float(group["weight_decay"]),
                                      1.0 - beta1 ** t, 1.0 - beta2 ** t, F_._stream()), "lic_adam_run")
+            # the kernel wrote through raw pointers: tell autograd (and prep.StepPrep, which re-derives the packed
+            # weights when a parameter's version moves) that the parameters and moments changed
+            torch.autograd.graph.increment_version(params + exp_avgs + exp_avg_sqs)
         self.fused_steps += 1
         return loss
 

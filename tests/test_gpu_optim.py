@@ -31,17 +31,24 @@ def test_fused_adam_matches_torch_adam(wd):
         ob.step()
     assert ob.fused_steps == 4
     for (n, pa), pb in zip(ma.named_parameters(), mb.parameters()):
-        scale = float(pa.abs().max())
-        assert float((pa - pb).abs().max()) <= 2e-6 * max(scale, 1e-3), n
+        # four updates of ~lr each; the two implementations round m / denom differently (operation order / fma)
+        assert float((pa.detach() - pb.detach()).abs().max()) <= 1e-5 * (4 * 3e-3) + 1e-6 * float(pa.detach().abs().max()), n
+        assert pb._version >= 4    # raw-pointer updates are reported to autograd (prep.StepPrep keys on versions)
     sa, sb = oa.state_dict(), ob.state_dict()
     assert sa["state"].keys() == sb["state"].keys()
     for k in sa["state"]:
         assert float(sa["state"][k]["step"]) == float(sb["state"][k]["step"]) == 4.0
         a, b = sa["state"][k]["exp_avg_sq"], sb["state"][k]["exp_avg_sq"]
         assert float((a - b).abs().max()) <= 1e-6 * max(float(a.abs().max()), 1e-12)
-    # a torch.optim.Adam state dict loads into FusedAdam and vice versa; the next steps agree again
+    # a torch.optim.Adam state dict loads into FusedAdam and vice versa
     ob.load_state_dict(sa)
     oa.load_state_dict(sb)
+    # the model trained with FusedAdam sees its NEW weights in the next forward (the step preparation re-packs)
+    with torch.no_grad():
+        out_b = mb(x, training=False)["x_hat"]
+        mb.use_step_prep = False
+        assert torch.equal(out_b, mb(x, training=False)["x_hat"])
+        mb.use_step_prep = True
     # amsgrad is not covered by the kernel: torch's implementation runs instead
     oc = FusedAdam(mb.parameters(), lr=1e-3, amsgrad=True)
     oc.step()
