@@ -412,8 +412,8 @@ typedef struct lic_adam_job {
 } lic_adam_job;
 int64_t lic_adam_plan(lic_adam_job* jobs, int32_t njobs);
 int lic_adam_run(const lic_adam_job* jobs_device, int32_t njobs, int64_t total_blocks, const float* const* grads_host,
-                 float lr, float beta1, float beta2, float eps, float weight_decay, float bias_correction1,
-                 float bias_correction2, lic_stream_t stream);
+                 double lr, double beta1, double beta2, double eps, double weight_decay, double bias_correction1,
+                 double bias_correction2, lic_stream_t stream);
 
 int lic_version(void);        /* LIC_ABI_VERSION */
 int lic_last_hip_error(void); /* hipError_t of the most recent failed launch on this thread */

@@ -123,7 +123,7 @@ SIGNATURES = {
     "lic_prep_plan": (_i64, [C.POINTER(PrepJob), _i32]),
     "lic_prep_run": (C.c_int, [_vp, _i32, _i64, _vp]),
     "lic_adam_plan": (_i64, [C.POINTER(AdamJob), _i32]),
-    "lic_adam_run": (C.c_int, [_vp, _i32, _i64, _vp, _f32, _f32, _f32, _f32, _f32, _f32, _f32, _vp]),
+    "lic_adam_run": (C.c_int, [_vp, _i32, _i64, _vp] + [C.c_double] * 7 + [_vp]),
     "lic_version": (C.c_int, []),
     "lic_last_hip_error": (C.c_int, []),
     "lic_arch": (C.c_char_p, []),

@@ -9,6 +9,7 @@
 //   p -= (lr / bias_correction1) * m / (sqrt(v) / sqrt(bias_correction2) + eps)
 // The bias corrections are computed on the host from the step count, as torch's default (non-capturable) path does.
 #include "lic_common.h"
+#include <math.h>
 
 namespace {
 constexpr int AD_ITEMS = 4096;  // elements per block
@@ -97,26 +98,30 @@ LIC_EXPORT int64_t lic_adam_plan(lic_adam_job* jobs, int32_t njobs) {
 
 template <int NG>
 static void adam_launch(const lic_adam_job* jobs_device, int njobs, long blocks, const float* const* grads, float lerp_w,
-                        float beta2, float eps, float wd, float step_size, float bc2_sqrt, hipStream_t s) {
+                        float beta2, float one_minus_beta2, float eps, float wd, float step_size, float bc2_sqrt,
+                        hipStream_t s) {
   AdamGrads<NG> a;
   for (int i = 0; i < NG; ++i) a.g[i] = i < njobs ? grads[i] : nullptr;
   hipLaunchKernelGGL((adam_kernel<NG>), dim3((unsigned)blocks), dim3(256), 0, s, jobs_device, njobs, a, lerp_w, beta2,
-                     1.0f - beta2, eps, wd, step_size, bc2_sqrt);
+                     one_minus_beta2, eps, wd, step_size, bc2_sqrt);
 }
 
 // grads_host: njobs gradient pointers (HOST array of DEVICE pointers), in job order; njobs <= 448
+// (scalars are doubles: torch derives 1 - beta, lr / bias_correction1 and sqrt(bias_correction2) in Python doubles
+// and rounds once to fp32; 1.0f - 0.999f is 1.7e-5 away from float(0.001))
 LIC_EXPORT int lic_adam_run(const lic_adam_job* jobs_device, int32_t njobs, int64_t total_blocks,
-                            const float* const* grads_host, float lr, float beta1, float beta2, float eps,
-                            float weight_decay, float bias_correction1, float bias_correction2, lic_stream_t stream) {
+                            const float* const* grads_host, double lr, double beta1, double beta2, double eps,
+                            double weight_decay, double bias_correction1, double bias_correction2, lic_stream_t stream) {
   if (!jobs_device || !grads_host || njobs <= 0 || total_blocks <= 0 || total_blocks > 0x7FFFFFFFL) return LIC_ERR_INVALID;
-  if (!(bias_correction1 > 0.0f) || !(bias_correction2 > 0.0f)) return LIC_ERR_INVALID;
+  if (!(bias_correction1 > 0.0) || !(bias_correction2 > 0.0)) return LIC_ERR_INVALID;
   if (njobs > 448) return LIC_ERR_UNSUPPORTED;
   for (int i = 0; i < njobs; ++i)
     if (!grads_host[i]) return LIC_ERR_INVALID;
-  const float lw = 1.0f - beta1, ss = lr / bias_correction1, bs = sqrtf(bias_correction2);
+  const float lw = (float)(1.0 - beta1), ss = (float)(lr / bias_correction1), bs = (float)sqrt(bias_correction2);
+  const float b2 = (float)beta2, omb2 = (float)(1.0 - beta2), ep = (float)eps, wd = (float)weight_decay;
   hipStream_t s = (hipStream_t)stream;
-  if (njobs <= 96) adam_launch<96>(jobs_device, njobs, total_blocks, grads_host, lw, beta2, eps, weight_decay, ss, bs, s);
-  else if (njobs <= 224) adam_launch<224>(jobs_device, njobs, total_blocks, grads_host, lw, beta2, eps, weight_decay, ss, bs, s);
-  else adam_launch<448>(jobs_device, njobs, total_blocks, grads_host, lw, beta2, eps, weight_decay, ss, bs, s);
+  if (njobs <= 96) adam_launch<96>(jobs_device, njobs, total_blocks, grads_host, lw, b2, omb2, ep, wd, ss, bs, s);
+  else if (njobs <= 224) adam_launch<224>(jobs_device, njobs, total_blocks, grads_host, lw, b2, omb2, ep, wd, ss, bs, s);
+  else adam_launch<448>(jobs_device, njobs, total_blocks, grads_host, lw, b2, omb2, ep, wd, ss, bs, s);
   return lic_check_launch();
 }
