@@ -1,1 +1,2 @@
-from neural_image_compression_amd.models import HierarchicalMixtureResidual, JointAutoregressiveHierarchical  # noqa: F401
+from neural_image_compression_amd.models import (HierarchicalMixtureResidual, JointAutoregressiveHierarchical,  # noqa: F401
+                                                 ScalableImageCoding)

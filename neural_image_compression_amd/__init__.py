@@ -9,9 +9,10 @@ import os as _os
 # Only effective if this import precedes the first HIP call of the process.
 _os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-from .models import JointAutoregressiveHierarchical, HierarchicalMixtureResidual  # noqa: F401
-from .loss import rd_loss  # noqa: F401
+from .models import JointAutoregressiveHierarchical, HierarchicalMixtureResidual, ScalableImageCoding  # noqa: F401
+from .loss import rd_loss, vision_rd_loss  # noqa: F401
 from .optim import FusedAdam  # noqa: F401
 from . import _lib  # noqa: F401
 
-__all__ = ["JointAutoregressiveHierarchical", "HierarchicalMixtureResidual", "rd_loss", "FusedAdam"]
+__all__ = ["JointAutoregressiveHierarchical", "HierarchicalMixtureResidual", "ScalableImageCoding", "rd_loss",
+           "vision_rd_loss", "FusedAdam"]

@@ -1,7 +1,6 @@
 """Analysis / synthesis / hyper stacks with the reference's class names, constructor
-signatures and `net.<i>` state-dict keys (reference: Components.py:6-122).
-`LatentSpaceTransform` (Components.py:125-153) is out of scope: it cannot execute upstream
-(SURVEY.md section 0)."""
+signatures and `net.<i>` state-dict keys (reference: Components.py:6-122), and
+`LatentSpaceTransform` (Components.py:125-153) with the one change that lets it execute (see the class)."""
 from __future__ import annotations
 
 import torch.nn as nn
@@ -118,3 +117,31 @@ class HyperDecoder3x3(_Stack):
             TransposedDeconv3x3(int(1.5 * M), int(1.5 * M), 2), LeakyReLU(inplace=True),
             Conv2d(int(1.5 * M), 2 * M, kernel_size=3, stride=1, padding=1),
         )
+
+
+class LatentSpaceTransform(nn.Module):
+    """Components.py:125-153: RB -> URB(up u0) -> RB -> URB(u1) -> RB -> URB(u2) -> RB -> conv3x3(C -> C*u3), attribute
+    names (state-dict keys) as the reference's.  ONE deliberate difference: the reference multiplies its CHANNEL
+    count by each SPATIAL upsampling factor (`latent_channels *= upsampling_factors[i]`, Components.py:130,134,138),
+    so with the only configuration it is used with, [2,1,1,1], `RB2` expects 2C channels, receives C and raises
+     -- the reference's class cannot run.  Here every block keeps C channels (what
+    `ResidualBlockUpsample(in_ch=C, out_ch=C)` produces), which is the smallest change that executes."""
+
+    def __init__(self, latent_channels=192, upsampling_factors=(2, 1, 1, 1)):
+        super().__init__()
+        C, u = int(latent_channels), [int(v) for v in upsampling_factors]
+        if len(u) != 4 or any(v < 1 or v > 2 for v in u[:3]):
+            raise ValueError("upsampling_factors: four entries, spatial factors 1 or 2")
+        self.RB1 = ResidualBlock(in_ch=C, out_ch=C)
+        self.URB1 = ResidualBlockUpsample(in_ch=C, out_ch=C, upsample=u[0])
+        self.RB2 = ResidualBlock(in_ch=C, out_ch=C)
+        self.URB2 = ResidualBlockUpsample(in_ch=C, out_ch=C, upsample=u[1])
+        self.RB3 = ResidualBlock(in_ch=C, out_ch=C)
+        self.URB3 = ResidualBlockUpsample(in_ch=C, out_ch=C, upsample=u[2])
+        self.RB4 = ResidualBlock(in_ch=C, out_ch=C)
+        self.conv = Conv2d(C, C * u[3], kernel_size=3, stride=1, padding=1)
+
+    def forward(self, x):
+        for blk in (self.RB1, self.URB1, self.RB2, self.URB2, self.RB3, self.URB3, self.RB4, self.conv):
+            x = blk(x)
+        return x

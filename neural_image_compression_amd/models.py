@@ -1,5 +1,6 @@
-"""Model classes with the reference's names and forward contract (reference: Models.py:10-205).
-`ScalableImageCoding` (Models.py:208-338) is out of scope: its forward raises upstream."""
+"""Model classes with the reference's names and forward contract (reference: Models.py:10-338).
+`ScalableImageCoding` (Models.py:208-338) cannot execute upstream; it is provided with the
+three one-line repairs that let it run, listed in its docstring."""
 from __future__ import annotations
 
 import os
@@ -9,7 +10,7 @@ import torch.nn as nn
 
 from . import functional as F_
 from .components import (Decoder3x3, Decoder5x5, Encoder3x3, Encoder5x5, HyperDecoder3x3, HyperDecoder5x5,
-                         HyperEncoder3x3, HyperEncoder5x5)
+                         HyperEncoder3x3, HyperEncoder5x5, LatentSpaceTransform)
 from .entropy import (ContextModel, EntropyParameters, FactorizedEntropyBottleneck, GaussianConditional,
                       GaussianMixtureConditional)
 
@@ -172,3 +173,71 @@ class JointAutoregressiveHierarchical(_HyperpriorContextModel):
 class HierarchicalMixtureResidual(_HyperpriorContextModel):
     """3x3 residual stacks (Models.py:109-205)."""
     _stacks = (Encoder3x3, Decoder3x3, HyperEncoder3x3, HyperDecoder3x3)
+
+
+class ScalableImageCoding(nn.Module):
+    """Models.py:208-338: the 5x5 model whose latent y is split into a base part y1 (`base_channels`) and an
+    enhancement part y2, each with its own masked context model and entropy-parameter MLP over the shared hyper
+    features, plus a `LatentSpaceTransform` of y1 (`F_tilde`, the features a frozen vision backbone is matched
+    against by `vision_rd_loss`).  Same constructor, attributes, state-dict keys and out-dict keys as the reference.
+    The reference's forward cannot run; the repairs made here, and nothing else:
+      * `self.factorized_entropy_model(z_in, debug)` (Models.py:302) passes a positional argument the entropy
+        model does not take -> called without it;
+      * in mixture mode the second parameter dict overwrites the first (`params1 = {...weights2...}`,
+        Models.py:298-299) -> it is `params2`;
+      * `LatentSpaceTransform` keeps its channel count (components.LatentSpaceTransform)."""
+
+    def __init__(self, latent_channels: int = 192, base_channels: int = 128, K: int = 1):
+        super().__init__()
+        if not isinstance(latent_channels, int) or latent_channels < 1:
+            raise ValueError(f"latent_channels must be int >= 1, got {latent_channels}")
+        if not isinstance(K, int) or K < 1:
+            raise ValueError(f"K must be int >= 1, got {K}")
+        if not isinstance(base_channels, int) or not 0 < base_channels < latent_channels:
+            raise ValueError(f"base_channels must be an int in (0, latent_channels), got {base_channels}")
+        self.M, self.M1, self.M2 = latent_channels, base_channels, latent_channels - base_channels
+        self.H, self.K = latent_channels, K
+        self.distribution = 'Mean-Scale Gaussian' if K == 1 else 'Mixture of Gaussians'
+        self.conditional = GaussianConditional() if K == 1 else GaussianMixtureConditional()
+        self.encoder = Encoder5x5(latent_channels=self.M)
+        self.decoder = Decoder5x5(latent_channels=self.M)
+        self.hyper_encoder = HyperEncoder5x5(latent_channels=self.M)
+        self.hyper_decoder = HyperDecoder5x5(latent_channels=self.M)
+        self.factorized_entropy_model = FactorizedEntropyBottleneck(self.M)
+        self.context_model_1 = ContextModel(latent_channels=self.M1)
+        self.context_model_2 = ContextModel(latent_channels=self.M2)
+        self.entropy_parameters_1 = EntropyParameters(latent_channels=self.M1, hyper_latent_channels=self.H, K=self.K)
+        self.entropy_parameters_2 = EntropyParameters(latent_channels=self.M2, hyper_latent_channels=self.H, K=self.K)
+        self.LST = LatentSpaceTransform(latent_channels=self.M1, upsampling_factors=[2, 1, 1, 1])
+
+    use_step_prep = _HyperpriorContextModel.use_step_prep
+    step_prep = _HyperpriorContextModel.step_prep
+
+    def forward(self, x: torch.Tensor, training: bool = True, debug=False, noise=None):
+        """`noise` (test hook, not in the reference): (u_z, u_y) used instead of torch.rand_like, z first."""
+        if x.shape[2] % 64 or x.shape[3] % 64:
+            raise RuntimeError("H and W must be multiples of 64 (phi/psi shapes must agree, Models.py:283-284)")
+        if self.use_step_prep and x.is_cuda:
+            self.step_prep().run()
+        y = self.encoder(x)
+        z = self.hyper_encoder(y)
+        if training:
+            uz, uy = noise if noise is not None else (torch.rand_like(z), torch.rand_like(y))
+            z_in, y_in = F_.quantize(z, uz, True), F_.quantize(y, uy, True)
+        else:
+            z_in, y_in = F_.quantize(z, None, False), F_.quantize(y, None, False)
+        y1, y2 = torch.split(y_in, [self.M1, self.M2], dim=1)
+        psi = self.hyper_decoder(z_in)
+        out = {'y': y, 'y_in': y_in, 'y1': y1, 'y2': y2, 'z': z, 'z_in': z_in, 'training': training}
+        params = {}
+        for tag, yk, ctx, ep in (("1", y1, self.context_model_1, self.entropy_parameters_1),
+                                 ("2", y2, self.context_model_2, self.entropy_parameters_2)):
+            act = ep.packed(torch.cat([ctx(yk), psi], dim=1))
+            names = ("mu", "sigma") if self.K == 1 else ("weights", "mus", "sigmas")
+            params.update({n + tag: v for n, v in zip(names, ep.split(act))})
+            out['p_y' + tag], out['logp_y' + tag] = self.conditional.packed_likelihood_and_log(yk, act, self.K)
+        out['p_z'], out['logp_z'] = self.factorized_entropy_model.likelihood_and_log(z_in)
+        out['x_hat'] = self.decoder(y_in)
+        out['F_tilde'] = self.LST(y1)
+        out.update(params)
+        return out

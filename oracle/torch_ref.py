@@ -223,6 +223,107 @@ def step(state: Dict[str, "object"], x, M, K, kind="5x5", noise=None, lambda_rd=
 
 
 # ----------------------------------------------------------------------------------------------
+# ScalableImageCoding / LatentSpaceTransform / vision_rd_loss (Models.py:208-338, Components.py:125-153,
+# RateDistortionLoss.py:52-121) with the three repairs the product states (models.ScalableImageCoding): the
+# reference's versions cannot execute, so there is nothing upstream to pin these against.
+# ----------------------------------------------------------------------------------------------
+def _rb_up_f(x, P, pre, up):
+    out = _lrelu(_convT(x, P, pre + ".subpel_conv.deconv", up, 1, up - 1))
+    out = _gdn(_conv(out, P, pre + ".conv", 1, 1), P, pre + ".igdn", True)
+    return out + _convT(x, P, pre + ".upsample.deconv", up, 1, up - 1)
+
+
+def latent_space_transform(x, P, pre="LST", ups=(2, 1, 1, 1)):
+    for i in range(3):
+        x = _rb_up_f(_rb(x, P, f"{pre}.RB{i + 1}"), P, f"{pre}.URB{i + 1}", ups[i])
+    return _conv(_rb(x, P, pre + ".RB4"), P, pre + ".conv", 1, 1)
+
+
+def _masked(yk, P, pre):
+    w = P[pre + ".masked.weight"]
+    mask = torch.ones_like(w)
+    mask[:, :, 2, 2:] = 0
+    mask[:, :, 3:] = 0
+    with torch.no_grad():
+        w.mul_(mask)
+    return F.conv2d(yk, w, P[pre + ".masked.bias"], padding=2)
+
+
+def _conditional(yk, raw, Mk, K):
+    if K == 1:
+        mu, sg = raw.chunk(2, dim=1)
+        sg = F.softplus(sg) + 1e-6
+        return (_gcdf((yk + 0.5 - mu) / sg) - _gcdf((yk - 0.5 - mu) / sg)).clamp_min(1e-9), (mu, sg)
+    B, _, hh, ww = raw.shape
+    wt, mus, sgs = (t.reshape(B, K, Mk, hh, ww) for t in raw.chunk(3, dim=1))
+    wt, sgs = F.softmax(wt, dim=1), F.softplus(sgs) + 1e-6
+    xe = yk.unsqueeze(1)
+    p = (wt * (_gcdf((xe + 0.5 - mus) / sgs) - _gcdf((xe - 0.5 - mus) / sgs))).sum(dim=1)
+    return p.clamp_min(1e-9), (wt, mus, sgs)
+
+
+def forward_scalable(P, x, M, M1, K, training=True, noise=None):
+    y = encoder(x, P, "5x5")
+    z = hyper_encoder(y, P, "5x5")
+    if training:
+        uz, uy = noise if noise is not None else (torch.rand_like(z), torch.rand_like(y))
+        z_in, y_in = z + (uz - 0.5), y + (uy - 0.5)
+    else:
+        z_in, y_in = torch.round(z), torch.round(y)
+    y1, y2 = torch.split(y_in, [M1, M - M1], dim=1)
+    psi = hyper_decoder(z_in, P, "5x5")
+    out = {"y": y, "y_in": y_in, "y1": y1, "y2": y2, "z": z, "z_in": z_in, "training": training}
+    for tag, yk, Mk in (("1", y1, M1), ("2", y2, M - M1)):
+        h = torch.cat([_masked(yk, P, "context_model_" + tag), psi], dim=1)
+        ep = f"entropy_parameters_{tag}.net."
+        h = _lrelu(_conv(h, P, ep + "0", 1, 0))
+        h = _lrelu(_conv(h, P, ep + "2", 1, 0))
+        p, par = _conditional(yk, _conv(h, P, ep + "4", 1, 0), Mk, K)
+        out["p_y" + tag], out["logp_y" + tag] = p, torch.log(p)
+        for n, v in zip(("mu", "sigma") if K == 1 else ("weights", "mus", "sigmas"), par):
+            out[n + tag] = v
+    p_z = _factorized(z_in, P).clamp_min(1e-9)
+    out.update(p_z=p_z, logp_z=torch.log(p_z), x_hat=decoder(y_in, P, "5x5"), F_tilde=latent_space_transform(y1, P))
+    return out
+
+
+def vision_rd_loss(out, x, lambda_rd, gamma, frozen_activation=None, V=None):
+    npix = x.size(2) * x.size(3)
+    bits = {k: -out["logp_" + k].sum(dim=(1, 2, 3)) / math.log(2.0) for k in ("y1", "y2", "z")}
+    bpp = {k: (v / npix).mean() for k, v in bits.items()}
+    rec_img = ((out["x_hat"] - x) ** 2).mean(dim=(1, 2, 3))
+    rec = rec_img.mean()
+    mse, vis = rec, None
+    if frozen_activation is not None and V is not None:
+        vis = ((frozen_activation(out["F_tilde"]) - V(out["x_hat"])) ** 2).mean(dim=(1, 2, 3)).mean()
+        mse = rec + gamma * vis
+    res = {"loss": bpp["y1"] + bpp["y2"] + bpp["z"] + lambda_rd * mse, "bpp_y1": bpp["y1"], "bpp_y2": bpp["y2"],
+           "bpp_z": bpp["z"], "bpp_total": bpp["y1"] + bpp["y2"] + bpp["z"], "mse": mse, "reconstruction_mse": rec,
+           "psnr": -10 * torch.log10(rec + 1e-8), "bits_y1": bits["y1"].mean(), "bits_y2": bits["y2"].mean(),
+           "bits_z": bits["z"].mean()}
+    if vis is not None:
+        res["vision_mse"] = vis
+    return res
+
+
+def step_scalable(state, x, M, M1, K, noise, lambda_rd, gamma, frozen_activation=None, V=None):
+    import numpy as np
+    P = {}
+    for k, v in state.items():
+        t = torch.as_tensor(np.asarray(v)).clone()
+        if t.is_floating_point() and k.split(".")[-1] not in ("pedestal", "bound", "mask"):
+            t.requires_grad_(True)
+        P[k] = t
+    xt = torch.as_tensor(np.asarray(x))
+    out = forward_scalable(P, xt, M, M1, K, True, tuple(torch.as_tensor(np.asarray(n)) for n in noise))
+    res = vision_rd_loss(out, xt, lambda_rd, gamma, frozen_activation, V)
+    res["loss"].backward()
+    grads = {k: v.grad.numpy() for k, v in P.items() if v.requires_grad and v.grad is not None}
+    return ({k: (v.detach().numpy() if torch.is_tensor(v) else v) for k, v in out.items()},
+            {k: float(v.detach()) for k, v in res.items()}, grads)
+
+
+# ----------------------------------------------------------------------------------------------
 # single layers (Components.py:12,41 at their real sizes: tests/test_gpu_variants.py)
 # ----------------------------------------------------------------------------------------------
 def _np(a):

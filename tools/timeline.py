@@ -10,9 +10,9 @@ def main():
     db = sqlite3.connect(sys.argv[1])
     back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
     rows = list(db.execute("select name, stream_id, start, end from kernels order by start"))
-    # a step starts at the first launch after Adam's last multi_tensor kernel
-    bounds = [i for i, r in enumerate(rows) if "multi_tensor_apply" in r[0] and
-              (i + 1 == len(rows) or "multi_tensor_apply" not in rows[i + 1][0])]
+    # a step starts at the first launch after the optimizer's last kernel
+    opt = lambda n: "multi_tensor_apply" in n or "adam_kernel" in n   # torch.optim.Adam / optim.FusedAdam
+    bounds = [i for i, r in enumerate(rows) if opt(r[0]) and (i + 1 == len(rows) or not opt(rows[i + 1][0]))]
     lo, hi = bounds[-back - 1] + 1, bounds[-back] + 1
     step = rows[lo:hi]
     t0, t1 = step[0][2], max(r[3] for r in step)
