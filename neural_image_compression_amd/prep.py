@@ -51,10 +51,15 @@ class StepPrep:
 
     # ------------------------------------------------------------------------------------------
     def _signature(self):
+        """what the job table was built for: device, precisions, parameter storage.  Walking `model.parameters()`
+        costs ~0.2 ms of host time, so the parameter list is cached and re-read only when a cheap sentinel (count
+        of registered parameters is not tracked by torch; the first and last storages are) moves."""
         m = self.model
         prec = tuple(getattr(getattr(m, n, None), "precision", "fp32") for n in _PRECISION_OWNERS)
-        p0 = next(m.parameters())
-        return (p0.device, prec, tuple(p.data_ptr() for p in m.parameters()))
+        plist = getattr(self, "_plist", None)
+        if plist is None:
+            plist = self._plist = list(m.parameters())
+        return (plist[0].device, prec, plist[0].data_ptr(), plist[-1].data_ptr(), len(plist))
 
     def _bf16_modules(self):
         ids = set()
@@ -141,7 +146,8 @@ class StepPrep:
         """Refresh the derived buffers if any parameter changed since they were built (one launch)."""
         sig = self._signature()
         if sig != self._sig:
-            self._sig = sig
+            self._plist = None          # storage moved (model.to(...), precision switch): re-read everything
+            self._sig = self._signature()
             self._build()
         if self._jobs_dev is None:
             return
