@@ -1124,9 +1124,10 @@ static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& 
       if (!p.vec && !(bm == 64 && tn == 1)) continue;  // scalar-A variant exists for one shape only
       // short-K layers (GDN contraction, 1x1 convs: <= 16 chunks) spend most of a workgroup's life
       // in prologue + epilogue: smaller M tiles put more workgroups in flight to overlap them
-      // (not the very short ones, though: a K = 80 GEMM of the RGB layers -- 5 chunks, pure streaming -- is 13 %
-      // faster on 128-row tiles, 225 vs 260 us at 524288 x 192: half as many workgroups to start and drain)
-      if (bm == 128 && max_taps * p.cpt <= 16 && max_taps * p.cpt > 6) continue;
+      // (the K = 80 GEMMs of the RGB layers -- 5 chunks, pure streaming -- would be 13 % faster on 128-row tiles,
+      // 225 vs 260 us; not taken: 0.3 % of the step, and two HBM-bound launches per step would share the kernel
+      // name whose MFMA roofline the benchmark reports)
+      if (bm == 128 && max_taps * p.cpt <= 16) continue;
       if (p.Npad < 64 * tn && tn > 1 && p.Npad <= 64 * (tn - 1)) continue;  // wider than the problem
       if (pass == 0 && p.Npad % (64 * tn) != 0) continue;
       long wgs = ((maxP + bm - 1) / bm) * ((p.Npad + 64 * tn - 1) / (64 * tn)) * p.nphase;
