@@ -265,6 +265,31 @@ int64_t lic_packed_weight_bf16_elems(int32_t taps, int32_t K, int32_t N);
 int lic_pack_weight_bf16(const float* src, void* dst, int32_t taps, int32_t K, int32_t N, int64_t s_tap,
                          int64_t s_k, int64_t s_n, lic_stream_t stream);
 int lic_igemm_bf16(const lic_igemm_desc* d, int32_t out_f32, lic_stream_t stream);
+/* lic_igemm_bf16 also runs LIC_EPI_CONV_GDN / LIC_EPI_CONV_IGDN (the conv -> GDN pairs of Components.py:10-15,
+ * 39-44 in one launch) when this returns 1 (Cout in {64,128,192}: one tile spans every output channel; bf16 `out`):
+ * aux = gamma_eff^T packed by lic_pack_weight_bf16_kperm(taps=1, K=Cout, N=Cout), aux2 = beta_eff (fp32 [Cout]),
+ * out3 / out2 = bf16 conv output / norm for the backward pass (either may be NULL: inference writes `out` only).
+ * The rounding points are those of LIC_EPI_NONE followed by the prologue=1 / LIC_EPI_GDN launch (x and x^2 to
+ * bf16, fp32 norm); the pool sums each group of 16 channels in a different order, so norms agree to fp32
+ * rounding, not bitwise. */
+int lic_igemm_bf16_fused_gdn_supported(int32_t Cin, int32_t Cout);
+/* lic_stem_gdn_bf16 -- the RGB stem of the analysis transform and the GDN behind it (Components.py:10-11:
+ * nn.Conv2d(3, C, 5, stride=2, padding=2) -> GDN(C)) in one launch that reads the fp32 NHWC image and writes the
+ * normalised bf16 feature map (no column matrix).  w_packed: lic_pack_stem_weight_bf16 of the [C][3][5][5] weight
+ * (lic_stem_weight_bf16_elems(C) bf16 elements); gamma_packed: gamma_eff^T by lic_pack_weight_bf16_kperm(taps 1,
+ * K = N = C); beta_eff fp32 [C]; y / conv_out / norm: bf16 [B][ceil(H/2)][ceil(W/2)][C], the last two may be NULL
+ * (they feed the backward pass).  Same rounding points as lic_igemm_bf16's LIC_EPI_CONV_GDN. */
+int lic_stem_gdn_bf16_supported(int32_t Cin, int32_t Cout, int32_t kh, int32_t kw, int32_t stride, int32_t pad);
+int64_t lic_stem_weight_bf16_elems(int32_t Cout);
+int lic_pack_stem_weight_bf16(const float* w, void* dst, int32_t Cout, lic_stream_t stream);
+int lic_stem_gdn_bf16(const float* x, const void* w_packed, const float* bias, const void* gamma_packed,
+                      const float* beta_eff, void* y, void* conv_out, void* norm, int32_t B, int32_t H, int32_t W,
+                      int32_t Cout, int32_t inverse, lic_stream_t stream);
+/* lic_pack_weight_bf16 with the K index permuted inside every group of 16: slot (h = 0..1, e = 0..7) of a group
+ * holds k = 8*(e/4) + 4*h + e%4 instead of 8*h + e -- the order in which a lane of the transposed accumulator
+ * tile owns channels, so the fused pool reads its x^2 operand from registers */
+int lic_pack_weight_bf16_kperm(const float* src, void* dst, int32_t taps, int32_t K, int32_t N, int64_t s_tap,
+                               int64_t s_k, int64_t s_n, lic_stream_t stream);
 /* names of the kernel variants lic_igemm_bf16 / lic_wgrad_bf16 launch for `d`, as rocprofv3 prints them
  * (force_bm of the descriptor is honoured; the N tile follows from the channel count) */
 int lic_igemm_bf16_kernel_name(const lic_igemm_desc* d, char* buf, size_t n);
@@ -376,7 +401,9 @@ int lic_tensor_stats(const float* x, int64_t n, int32_t nbins, float lo, float h
  *   array to device memory once, then lic_prep_run once per optimizer step.  Results are bit-identical to
  *   the stand-alone entry points.
  * ------------------------------------------------------------------------------------------ */
-enum lic_prep_kind { LIC_PREP_PACK_F32 = 0, LIC_PREP_PACK_BF16 = 1, LIC_PREP_MAP = 2, LIC_PREP_MASK_INPLACE = 3 };
+enum lic_prep_kind { LIC_PREP_PACK_F32 = 0, LIC_PREP_PACK_BF16 = 1, LIC_PREP_MAP = 2, LIC_PREP_MASK_INPLACE = 3,
+                     LIC_PREP_PACK_BF16_KPERM = 4 /* lic_pack_weight_bf16_kperm's order */,
+                     LIC_PREP_PACK_BF16_STEM = 5  /* lic_pack_stem_weight_bf16: src = [N][3][5][5], K = 80 */ };
 typedef struct lic_prep_job {
   const float* src;
   void* dst;

@@ -43,7 +43,7 @@ class WgradDesc(C.Structure):
                 ("force_tm", _i32), ("force_tn", _i32), ("force_split", _i32)]
 
 
-PREP_PACK_F32, PREP_PACK_BF16, PREP_MAP, PREP_MASK_INPLACE = range(4)
+PREP_PACK_F32, PREP_PACK_BF16, PREP_MAP, PREP_MASK_INPLACE, PREP_PACK_BF16_KPERM, PREP_PACK_BF16_STEM = range(6)
 
 
 class PrepJob(C.Structure):
@@ -95,8 +95,14 @@ SIGNATURES = {
     "lic_rd_loss_bwd": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i32, _i64, _f32, _vp, _vp, _vp, _vp, _vp]),
     "lic_packed_weight_bf16_elems": (_i64, [_i32, _i32, _i32]),
     "lic_pack_weight_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _vp]),
+    "lic_pack_weight_bf16_kperm": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _vp]),
     "lic_igemm_bf16": (C.c_int, [C.POINTER(IgemmDesc), _i32, _vp]),
     "lic_igemm_bf16_kernel_name": (C.c_int, [C.POINTER(IgemmDesc), C.c_char_p, _sz]),
+    "lic_igemm_bf16_fused_gdn_supported": (C.c_int, [_i32, _i32]),
+    "lic_stem_gdn_bf16_supported": (C.c_int, [_i32] * 6),
+    "lic_stem_weight_bf16_elems": (C.c_int64, [_i32]),
+    "lic_pack_stem_weight_bf16": (C.c_int, [_vp, _vp, _i32, _vp]),
+    "lic_stem_gdn_bf16": (C.c_int, [_vp] * 8 + [_i32] * 5 + [_vp]),
     "lic_wgrad_bf16_kernel_name": (C.c_int, [C.POINTER(WgradDesc), C.c_char_p, _sz]),
     "lic_wgrad_bf16_workspace_bytes": (_sz, [C.POINTER(WgradDesc)]),
     "lic_wgrad_bf16": (C.c_int, [C.POINTER(WgradDesc), _vp, _sz, _vp]),

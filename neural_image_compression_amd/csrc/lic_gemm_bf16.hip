@@ -42,7 +42,9 @@ struct IgemmHParams {
   const bf16_t* aux;
   const bf16_t* aux2;
   const bf16_t* aux3;
-  long in_ld, out_ld, out2_ld, aux_ld, aux2_ld, aux3_ld;
+  bf16_t* out3;        // FUSE: the convolution output before the normalisation (bf16), or null
+  const float* beta;   // FUSE: beta_eff [Cout] (p.aux = gamma_eff^T packed like a 1x1 weight)
+  long in_ld, out_ld, out2_ld, aux_ld, aux2_ld, aux3_ld, out3_ld;
   int B, Hi, Wi, Cin, Ho, Wo, Cout;
   int kw, stride, pad, transposed, prologue, epilogue, out_f32;
   float slope;  // LIC_EPI_LEAKY
@@ -66,11 +68,23 @@ __device__ __forceinline__ bf16x8 sq8(bf16x8 v) {
 
 // SQ: prologue 1 (GDN pool: the operand is x^2), squared at the fragment read.  A template flag: as a
 // runtime condition hipcc computes the squares in every launch and selects (100 VALU per 12-MFMA chunk).
-template <int BM, int TN, bool SQ = false>
+// FUSE: LIC_EPI_CONV_GDN / CONV_IGDN -- the tile holds every output channel of its pixels (NT == 1), so the
+// workgroup that convolved them also pools them.  The four waves then sit side by side along M (32 pixels x all
+// channels each) and run the MFMAs with the operands swapped, so the accumulators hold the TRANSPOSED tile: lane
+// (li, lh) owns pixel li and, of every 32-channel tile, channels 4*lh + 8*g + j (g, j = 0..3).  Eight of those
+// (g = 2s, 2s+1) are exactly one lane's share of a 16-deep MFMA B operand if K is counted in that order, which is
+// how lic_pack_weight_bf16_kperm lays gamma_eff^T out: x -> bf16, x^2 -> bf16 and the pool's operand never leave
+// the registers (no LDS transpose, no barrier), y = x * rsqrt(norm) is element-wise in the same layout, and one
+// v_permlane32_swap per dword pair turns a lane's 4+4 channels into 8 consecutive ones for 16-byte stores.
+// The element-wise part is written with 2-wide vectors (v_pk_add/mul_f32, v_cvt_pk_bf16_f32): at 2^26 outputs
+// per launch of the first layer every VALU instruction per element is 1.7 us.
+template <int BM, int TN, bool SQ = false, bool FUSE = false>
 __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
   constexpr int BN = 64 * TN;
-  constexpr int WM = BM / 2, WN = BN / 2;
-  constexpr int TM = WM / 32;
+  constexpr int WGN = FUSE ? 1 : 2, WGM = 4 / WGN;  // wave grid
+  constexpr int WM = BM / WGM, WN = BN / WGN;
+  constexpr int TM = WM / 32, TW = WN / 32;         // 32x32 MFMA tiles per wave
+  static_assert(!FUSE || (BM == 128 && !SQ), "the fused pool runs on 128-row tiles");
   constexpr int APASS = BM / 64;              // 16-byte DMA pieces per thread per A tile
   constexpr int NL = APASS + TN;              // DMA instructions per thread per chunk
   constexpr int BUF = (BM + BN) * HB_BK;      // bf16 elements of one (A tile, B panel) buffer
@@ -83,7 +97,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  const int wm0 = (wave / WGN) * WM, wn0 = (wave % WGN) * WN;
   const int li = lane & 31, lh = lane >> 5;
 
   const int nwg = gridDim.x;
@@ -141,11 +155,11 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
     }
   }
 
-  f32x16 acc[TM][TN];
+  f32x16 acc[TM][TW];
 #pragma unroll
   for (int a = 0; a < TM; ++a)
 #pragma unroll
-    for (int b = 0; b < TN; ++b)
+    for (int b = 0; b < TW; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.0f;
 
@@ -209,7 +223,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
     constexpr int buf = decltype(bufc)::value;
     const bf16_t* bA = bufp(buf);
     const bf16_t* bB = bA + BM * HB_BK + (wn0 >> 5) * 1024 + lane * 8;
-    bf16x8 af[TM][2], bf[TN][2];
+    bf16x8 af[TM][2], bf[TW][2];
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
       const int row = wm0 + a * 32 + li;
@@ -221,16 +235,20 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
       }
     }
 #pragma unroll
-    for (int b = 0; b < TN; ++b)
+    for (int b = 0; b < TW; ++b)
 #pragma unroll
       for (int q = 0; q < 2; ++q) bf[b][q] = *reinterpret_cast<const bf16x8*>(bB + (b * 2 + q) * 512);
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
-      for (int b = 0; b < TN; ++b)
+      for (int b = 0; b < TW; ++b)
 #pragma unroll
-        for (int a = 0; a < TM; ++a)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][q], bf[b][q], acc[a][b], 0, 0, 0);
+        for (int a = 0; a < TM; ++a) {
+          if constexpr (FUSE)  // transposed tile: channels down the rows, pixels across the lanes
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bf[b][q], af[a][q], acc[a][b], 0, 0, 0);
+          else
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a][q], bf[b][q], acc[a][b], 0, 0, 0);
+        }
   };
 
   int l_tap = 0, l_cb = 0;
@@ -276,10 +294,107 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
   const int epi = p.epilogue;
   float* stg = reinterpret_cast<float*>(smem_all) + wave * 1024;
   const int c8 = (lane & 3) * 8, r16 = lane >> 2;
+  if constexpr (FUSE) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    auto pack2 = [](f32x2 v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)); };
+    // this lane's pixel (TM == 1) and where it lives in the output tensors
+    const int prow = m0 + wm0 + li;
+    const bool rok = prow < P;
+    long opix = rok ? prow : 0;
+    if (p.nphase > 1) {
+      const int bb = fdivb((int)opix, p.dHW[phase]);
+      const int rem = (int)opix - bb * Hq * Wq;
+      const int i = fdivb(rem, p.dW[phase]), jj = rem - i * Wq;
+      opix = ((long)bb * p.Ho + i * sph + py) * p.Wo + jj * sph + px;
+    }
+    // a lane's 16 channels of tile b as 8 bf16 pairs -> two 16-byte stores of 8 consecutive channels each
+    auto store_tile = [&](bf16_t* base, long ld, const unsigned (&pk)[8], int b) {
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const u32x2 r0 = __builtin_amdgcn_permlane32_swap(pk[4 * s], pk[4 * s + 2], false, false);
+        const u32x2 r1 = __builtin_amdgcn_permlane32_swap(pk[4 * s + 1], pk[4 * s + 3], false, false);
+        if (rok) {
+          const u32x4 v = {r0[0], r1[0], r0[1], r1[1]};
+          *reinterpret_cast<u32x4*>(base + opix * ld + b * 32 + 16 * s + 8 * lh) = v;
+        }
+      }
+    };
+    // 1. x = conv + bias, rounded to bf16 (what the backward pass reads); x^2 rounded again: the pool's operand
+    unsigned sqpk[TW][8];
+#pragma unroll
+    for (int b = 0; b < TW; ++b) {
+      unsigned xpk[8];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 bs = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (p.bias) bs = *reinterpret_cast<const f32x4*>(p.bias + b * 32 + 4 * lh + 8 * g);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const f32x2 v = {acc[0][b][4 * g + 2 * h] + bs[2 * h], acc[0][b][4 * g + 2 * h + 1] + bs[2 * h + 1]};
+          const unsigned pk = pack2(v);
+          xpk[2 * g + h] = pk;
+          const f32x2 xb = {__builtin_bit_cast(float, pk << 16), __builtin_bit_cast(float, pk & 0xffff0000u)};
+          acc[0][b][4 * g + 2 * h] = xb[0];
+          acc[0][b][4 * g + 2 * h + 1] = xb[1];
+          sqpk[b][2 * g + h] = pack2(xb * xb);
+        }
+      }
+      if (p.out3) store_tile(p.out3, p.out3_ld, xpk, b);
+    }
+    // 2. norm^T = gamma_eff . (x^2)^T: A fragments of gamma_eff^T straight from L2 (16 bytes per lane, fragment order)
+    f32x16 nacc[TW];
+#pragma unroll
+    for (int b = 0; b < TW; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) nacc[b][r] = 0.0f;
+    const bf16_t* gA = p.aux + lane * 8;
+    const int ntile = p.Npad >> 5;
+#pragma unroll
+    for (int t = 0; t < TW; ++t)
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        const u32x4 bq = {sqpk[t][4 * s], sqpk[t][4 * s + 1], sqpk[t][4 * s + 2], sqpk[t][4 * s + 3]};
+        const bf16x8 b2 = __builtin_bit_cast(bf16x8, bq);
+#pragma unroll
+        for (int bo = 0; bo < TW; ++bo) {
+          const bf16x8 a2 = *reinterpret_cast<const bf16x8*>(gA + ((long)t * ntile + bo) * 1024 + s * 512);
+          nacc[bo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, nacc[bo], 0, 0, 0);
+        }
+      }
+    // 3. y = x * norm^-1/2 (GDN) or x * norm^1/2 (IGDN), element-wise in the accumulator layout
+    auto finish = [&](auto inv) {
+      constexpr bool INV = decltype(inv)::value;
+#pragma unroll
+      for (int b = 0; b < TW; ++b) {
+        unsigned npk[8], ypk[8];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + b * 32 + 4 * lh + 8 * g);
+#pragma unroll
+          for (int h = 0; h < 2; ++h) {
+            const f32x2 nv = {nacc[b][4 * g + 2 * h] + be[2 * h], nacc[b][4 * g + 2 * h + 1] + be[2 * h + 1]};
+            npk[2 * g + h] = pack2(nv);
+            const f32x2 f = {INV ? __builtin_amdgcn_sqrtf(nv[0]) : __builtin_amdgcn_rsqf(nv[0]),
+                             INV ? __builtin_amdgcn_sqrtf(nv[1]) : __builtin_amdgcn_rsqf(nv[1])};
+            const f32x2 xv = {acc[0][b][4 * g + 2 * h], acc[0][b][4 * g + 2 * h + 1]};
+            ypk[2 * g + h] = pack2(xv * f);
+          }
+        }
+        if (p.out2) store_tile(p.out2, p.out2_ld, npk, b);
+        store_tile(reinterpret_cast<bf16_t*>(p.out), p.out_ld, ypk, b);
+      }
+    };
+    if (epi == LIC_EPI_CONV_IGDN) finish(std::true_type{});
+    else finish(std::false_type{});
+    return;
+  }
 #pragma unroll
   for (int a = 0; a < TM; ++a)
 #pragma unroll
-    for (int b = 0; b < TN; ++b) {
+    for (int b = 0; b < TW; ++b) {
       __builtin_amdgcn_wave_barrier();  // wave-private patch
 #pragma unroll
       for (int r = 0; r < 16; ++r) stg[((r & 3) + 8 * (r >> 2) + 4 * lh) * 32 + li] = acc[a][b][r];
@@ -358,12 +473,16 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
 
 static bool al16h(const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
+LIC_EXPORT int lic_igemm_bf16_fused_gdn_supported(int32_t Cin, int32_t Cout) {
+  return (Cout == 64 || Cout == 128 || Cout == 192) && Cin > 0 && Cin % 8 == 0;
+}
+
 // ---- weight packing to bf16: dst[tap][chunk][n/32][kstep][lane][8], zero padded (K to 32, N to 64).
 // Lane (col = lane&31, h = lane>>5) of a wave owns k = 16*kstep + 8h + e of column 32*tile + col:
 // the B fragment of one 32x32x16 MFMA is lane*16 B of one contiguous KiB.
 __global__ __launch_bounds__(256) void pack_weight_bf16_kernel(const float* src, bf16_t* dst, int taps, int K,
                                                                int N, int cpt, int Npad, long s_tap, long s_k,
-                                                               long s_n) {
+                                                               long s_n, int kperm) {
   const long total = (long)taps * cpt * Npad * HB_BK;
   const int ntile = Npad >> 5;
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -374,7 +493,7 @@ __global__ __launch_bounds__(256) void pack_weight_bf16_kernel(const float* src,
     const int cb = (int)(t % cpt);
     const int tap = (int)(t / cpt);
     const int n = tile * 32 + (lane & 31);
-    const int k = cb * HB_BK + q * 16 + (lane >> 5) * 8 + e;
+    const int k = cb * HB_BK + q * 16 + (kperm ? ((e >> 2) * 8 + (lane >> 5) * 4 + (e & 3)) : ((lane >> 5) * 8 + e));
     dst[i] = (bf16_t)((k < K && n < N) ? src[tap * s_tap + k * s_k + n * s_n] : 0.0f);
   }
 }
@@ -382,14 +501,22 @@ LIC_EXPORT int64_t lic_packed_weight_bf16_elems(int32_t taps, int32_t K, int32_t
   if (taps <= 0 || K <= 0 || N <= 0) return 0;
   return (int64_t)taps * ((K + HB_BK - 1) / HB_BK) * (((N + 63) / 64) * 64) * HB_BK;
 }
-LIC_EXPORT int lic_pack_weight_bf16(const float* src, void* dst, int32_t taps, int32_t K, int32_t N,
-                                    int64_t s_tap, int64_t s_k, int64_t s_n, lic_stream_t stream) {
+static int pack_bf16_launch(const float* src, void* dst, int32_t taps, int32_t K, int32_t N, int64_t s_tap, int64_t s_k,
+                            int64_t s_n, int kperm, lic_stream_t stream) {
   if (!src || !dst || taps <= 0 || K <= 0 || N <= 0) return LIC_ERR_INVALID;
   const int cpt = (K + HB_BK - 1) / HB_BK, Npad = ((N + 63) / 64) * 64;
   const long total = (long)taps * cpt * Npad * HB_BK;
   hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, (hipStream_t)stream, src,
-                     (bf16_t*)dst, taps, K, N, cpt, Npad, (long)s_tap, (long)s_k, (long)s_n);
+                     (bf16_t*)dst, taps, K, N, cpt, Npad, (long)s_tap, (long)s_k, (long)s_n, kperm);
   return lic_check_launch();
+}
+LIC_EXPORT int lic_pack_weight_bf16(const float* src, void* dst, int32_t taps, int32_t K, int32_t N,
+                                    int64_t s_tap, int64_t s_k, int64_t s_n, lic_stream_t stream) {
+  return pack_bf16_launch(src, dst, taps, K, N, s_tap, s_k, s_n, 0, stream);
+}
+LIC_EXPORT int lic_pack_weight_bf16_kperm(const float* src, void* dst, int32_t taps, int32_t K, int32_t N,
+                                          int64_t s_tap, int64_t s_k, int64_t s_n, lic_stream_t stream) {
+  return pack_bf16_launch(src, dst, taps, K, N, s_tap, s_k, s_n, 1, stream);
 }
 
 // d uses the lic_igemm_desc layout; activation / aux / out2 pointers are bf16, `w` is the bf16
@@ -402,14 +529,21 @@ static int igemmh_prepare(const lic_igemm_desc* d, int32_t out_f32, IgemmHParams
     return LIC_ERR_INVALID;
   if (d->kh * d->kw > 28 || d->stride < 1 || d->stride > 2) return LIC_ERR_UNSUPPORTED;
   const int epi = d->epilogue;
+  const bool fuse = (epi == LIC_EPI_CONV_GDN || epi == LIC_EPI_CONV_IGDN);
   if (!(epi == LIC_EPI_NONE || epi == LIC_EPI_LEAKY || epi == LIC_EPI_GDN || epi == LIC_EPI_IGDN ||
-        epi == LIC_EPI_GDN_BWD || epi == LIC_EPI_IGDN_BWD) || d->res)
+        epi == LIC_EPI_GDN_BWD || epi == LIC_EPI_IGDN_BWD || fuse) || d->res)
     return LIC_ERR_UNSUPPORTED;
   if ((epi == LIC_EPI_GDN || epi == LIC_EPI_IGDN) && !d->aux) return LIC_ERR_INVALID;
+  if (fuse) {  // aux = gamma_eff^T packed (taps 1, K = N = Cout), aux2 = beta_eff (fp32); the tile spans every channel
+    if (!d->aux || !d->aux2 || d->prologue) return LIC_ERR_INVALID;
+    if (!lic_igemm_bf16_fused_gdn_supported(d->Cin, d->Cout)) return LIC_ERR_UNSUPPORTED;
+    if ((d->out3 && d->out3_ld % 8) || !al16h(d->out3)) return LIC_ERR_INVALID;
+    if (out_f32) return LIC_ERR_UNSUPPORTED;
+  }
   if ((epi == LIC_EPI_GDN_BWD || epi == LIC_EPI_IGDN_BWD) && (!d->aux || !d->aux2 || !d->aux3)) return LIC_ERR_INVALID;
   // bf16 path: 16-byte pieces everywhere -> channel counts and pitches multiples of 8
   if (d->Cin % 8 || d->Cout % 8 || d->in_ld % 8 || d->out_ld % 8 || (d->out2 && d->out2_ld % 8) ||
-      (d->aux && d->aux_ld % 8) || (d->aux2 && d->aux2_ld % 8) || (d->aux3 && d->aux3_ld % 8))
+      (!fuse && ((d->aux && d->aux_ld % 8) || (d->aux2 && d->aux2_ld % 8))) || (d->aux3 && d->aux3_ld % 8))
     return LIC_ERR_UNSUPPORTED;
   if (!al16h(d->in) || !al16h(d->w) || !al16h(d->out) || !al16h(d->out2) || !al16h(d->aux) || !al16h(d->aux2) ||
       !al16h(d->aux3))
@@ -422,6 +556,9 @@ static int igemmh_prepare(const lic_igemm_desc* d, int32_t out_f32, IgemmHParams
   p.aux = (const bf16_t*)d->aux;
   p.aux2 = (const bf16_t*)d->aux2;
   p.aux3 = (const bf16_t*)d->aux3;
+  p.out3 = fuse ? (bf16_t*)d->out3 : nullptr;
+  p.beta = fuse ? d->aux2 : nullptr;
+  p.out3_ld = d->out3_ld;
   p.in_ld = d->in_ld;
   p.out_ld = d->out_ld;
   p.out2_ld = d->out2_ld;
@@ -486,6 +623,7 @@ static int igemmh_prepare(const lic_igemm_desc* d, int32_t out_f32, IgemmHParams
     if (d->force_bm != 64 && d->force_bm != 128) return LIC_ERR_UNSUPPORTED;
     BM = d->force_bm;
   }
+  if (fuse) BM = 128;  // (the fused pool's wave layout)
   if (d->force_tn && d->force_tn != TN) return LIC_ERR_UNSUPPORTED;
   p.MT = (int)((maxP + BM - 1) / BM);
   p.pgroup = 0;
@@ -515,7 +653,9 @@ LIC_EXPORT int lic_igemm_bf16_kernel_name(const lic_igemm_desc* d, char* buf, si
   const int rc = igemmh_prepare(d, 0, p, BM, TN, nwg);
   if (rc < 0) return rc;
   if (!buf || n == 0) return LIC_ERR_INVALID;
-  snprintf(buf, n, "igemm_bf16_kernel<%d, %d, %s>", BM, TN, p.prologue == 1 ? "true" : "false");
+  const bool fuse = p.epilogue == LIC_EPI_CONV_GDN || p.epilogue == LIC_EPI_CONV_IGDN;
+  snprintf(buf, n, fuse ? "igemm_bf16_kernel<%d, %d, %s, true>" : "igemm_bf16_kernel<%d, %d, %s>", BM, TN,
+           p.prologue == 1 ? "true" : "false");
   return LIC_OK;
 }
 
@@ -528,12 +668,15 @@ LIC_EXPORT int lic_igemm_bf16(const lic_igemm_desc* d, int32_t out_f32, lic_stre
   if (rc == 1) return LIC_OK;
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)nwg), block(256);
-#define LIC_IGEMMH_LAUNCH(bm, tn)                                                        \
-  do {                                                                                   \
-    if (p.prologue == 1)                                                                 \
-      hipLaunchKernelGGL((igemm_bf16_kernel<bm, tn, true>), grid, block, 0, s, p);       \
-    else                                                                                 \
-      hipLaunchKernelGGL((igemm_bf16_kernel<bm, tn>), grid, block, 0, s, p);             \
+  const bool fuse = p.epilogue == LIC_EPI_CONV_GDN || p.epilogue == LIC_EPI_CONV_IGDN;
+#define LIC_IGEMMH_LAUNCH(bm, tn)                                                           \
+  do {                                                                                      \
+    if (fuse)                                                                               \
+      hipLaunchKernelGGL((igemm_bf16_kernel<128, tn, false, true>), grid, block, 0, s, p);  \
+    else if (p.prologue == 1)                                                               \
+      hipLaunchKernelGGL((igemm_bf16_kernel<bm, tn, true>), grid, block, 0, s, p);          \
+    else                                                                                    \
+      hipLaunchKernelGGL((igemm_bf16_kernel<bm, tn>), grid, block, 0, s, p);                \
   } while (0)
   if (BM == 128 && TN == 3)
     LIC_IGEMMH_LAUNCH(128, 3);

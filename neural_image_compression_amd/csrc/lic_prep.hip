@@ -76,7 +76,14 @@ __device__ void pp_pack_bf16(const lic_prep_job& j, int blk) {
     const int cb = (int)(t % j.cpt);
     const int tap = (int)(t / j.cpt);
     const int n = tile * 32 + (lane & 31);
-    const int k = cb * PP_HBK + q * 16 + (lane >> 5) * 8 + e;
+    // (KPERM: the K order of lic_igemm_bf16's fused GDN pool, whose operand comes straight from accumulator registers)
+    const int kin = (j.kind == LIC_PREP_PACK_BF16_KPERM) ? ((e >> 2) * 8 + (lane >> 5) * 4 + (e & 3)) : ((lane >> 5) * 8 + e);
+    const int k = cb * PP_HBK + q * 16 + kin;
+    if (j.kind == LIC_PREP_PACK_BF16_STEM) {  // lic_pack_stem_weight_bf16: K = 16*r + 3*s + c of a [N][3][5][5] weight
+      const int r = k >> 4, jj = k & 15, s = jj / 3;
+      dst[i] = (bf16_t)((r < 5 && jj < 15 && n < j.N) ? j.src[n * 75 + (jj - 3 * s) * 25 + r * 5 + s] : 0.0f);
+      continue;
+    }
     dst[i] = (bf16_t)((k < j.K && n < j.N) ? pp_value(j, pp_offset(j, tap, k, n)) : 0.0f);
   }
 }
@@ -197,7 +204,7 @@ __global__ __launch_bounds__(256) void prep_kernel(const lic_prep_job* jobs, int
     if (job.tiled == 1) pp_pack_tiled<true>(job, blk, st);
     else if (job.tiled == 2) pp_pack_tiled<false>(job, blk, st);
     else pp_pack_f32(job, blk);
-  } else if (job.kind == LIC_PREP_PACK_BF16) {
+  } else if (job.kind == LIC_PREP_PACK_BF16 || job.kind == LIC_PREP_PACK_BF16_KPERM || job.kind == LIC_PREP_PACK_BF16_STEM) {
     pp_pack_bf16(job, blk);
   } else {
     pp_map(job, blk);
@@ -218,9 +225,14 @@ LIC_EXPORT int64_t lic_prep_plan(lic_prep_job* jobs, int32_t njobs) {
     if (!j.src) return LIC_ERR_INVALID;
     j.tiled = j.v4 = 0;
     j.cpt = j.npad = 0;
-    if (j.kind == LIC_PREP_PACK_F32 || j.kind == LIC_PREP_PACK_BF16) {
+    if (j.kind == LIC_PREP_PACK_BF16_STEM) {
+      j.taps = 1;
+      j.K = 80;
+    }
+    if (j.kind == LIC_PREP_PACK_F32 || j.kind == LIC_PREP_PACK_BF16 || j.kind == LIC_PREP_PACK_BF16_KPERM ||
+        j.kind == LIC_PREP_PACK_BF16_STEM) {
       if (!j.dst || j.taps <= 0 || j.K <= 0 || j.N <= 0 || !pp_al16(j.dst)) return LIC_ERR_INVALID;
-      const bool h = j.kind == LIC_PREP_PACK_BF16;
+      const bool h = j.kind != LIC_PREP_PACK_F32;
       const int bk = h ? PP_HBK : PP_BK;
       j.cpt = (j.K + bk - 1) / bk;
       j.npad = h ? ((j.N + 63) / 64) * 64 : lic_npad_f32(j.N);

@@ -31,11 +31,11 @@ def _as_bf16_nhwc(t: torch.Tensor) -> torch.Tensor:
     return th if th.dtype == BF16 else th.to(BF16)
 
 
-def _pack_bf16(src: torch.Tensor, taps, K, N, s_tap, s_k, s_n) -> torch.Tensor:
+def _pack_bf16(src: torch.Tensor, taps, K, N, s_tap, s_k, s_n, kperm=False) -> torch.Tensor:
     lib = L.load()
     out = torch.empty((lib.lic_packed_weight_bf16_elems(taps, K, N),), device=src.device, dtype=BF16)
-    L.check(lib.lic_pack_weight_bf16(_ptr(src), _ptr(out), taps, K, N, s_tap, s_k, s_n, _stream()),
-            "lic_pack_weight_bf16")
+    fn = lib.lic_pack_weight_bf16_kperm if kperm else lib.lic_pack_weight_bf16
+    L.check(fn(_ptr(src), _ptr(out), taps, K, N, s_tap, s_k, s_n, _stream()), "lic_pack_weight_bf16")
     return out
 
 
@@ -56,12 +56,13 @@ def _pack_conv_weight_bf16(w, transposed_weight, for_dgrad):
 
 
 def _igemm_bf16(inp, w_packed, out, *, B, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, pad, transposed, bias=None,
-                prologue=0, epilogue=L.EPI_NONE, out2=None, aux=None, aux2=None, aux3=None, slope=0.01, tap_mask=0):
+                prologue=0, epilogue=L.EPI_NONE, out2=None, aux=None, aux2=None, aux3=None, slope=0.01, tap_mask=0,
+                out3=None):
     d = L.IgemmDesc()
     d.in_, d.w, d.bias, d.out, d.out2 = _ptr(inp), _ptr(w_packed), _ptr(bias), _ptr(out), _ptr(out2)
-    d.aux, d.aux2, d.aux3, d.res = _ptr(aux), _ptr(aux2), _ptr(aux3), None
+    d.aux, d.aux2, d.aux3, d.res, d.out3 = _ptr(aux), _ptr(aux2), _ptr(aux3), None, _ptr(out3)
     d.in_ld, d.out_ld = Cin, Cout
-    d.out2_ld = d.aux_ld = d.aux2_ld = d.aux3_ld = d.res_ld = Cout
+    d.out2_ld = d.aux_ld = d.aux2_ld = d.aux3_ld = d.res_ld = d.out3_ld = Cout
     d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout = B, Hi, Wi, Cin, Ho, Wo, Cout
     d.kh, d.kw, d.stride, d.pad = kh, kw, stride, pad
     d.transposed, d.prologue, d.epilogue = int(transposed), prologue, epilogue
@@ -159,28 +160,36 @@ class _ConvBF16Fn(torch.autograd.Function):
         g = _as_bf16_nhwc(gy)
         if leaky:
             g = _leaky_bwd_bf16(yh, g, slope)
-        B, Hi, Wi, Cin = xh.shape
-        _, Ho, Wo, Cout = g.shape
-        kh, kw = weight.shape[2], weight.shape[3]
-        taps = kh * kw
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            wp = _pack_conv_weight_bf16(weight, transposed, True)
-            dxh = torch.empty((B, Hi, Wi, Cin), device=g.device, dtype=in_dtype)
-            _igemm_bf16(g, wp, dxh, B=B, Hi=Ho, Wi=Wo, Cin=Cout, Ho=Hi, Wo=Wi, Cout=Cin, kh=kh, kw=kw, stride=stride,
-                        pad=pad, transposed=not transposed, tap_mask=tap_mask)
-            dx = _nchw_view(dxh)
-        if ctx.needs_input_grad[1]:
-            dw = grad_like(weight)
-            if transposed:
-                _wgrad_bf16(xh, g, dw, B=B, Hs=Hi, Ws=Wi, Cp=Cin, Hl=Ho, Wl=Wo, Cg=Cout, kh=kh, kw=kw, stride=stride,
-                            pad=pad, g_is_row=False, dst_sm=Cout * taps, dst_sn=taps, dst_stap=1)
-            else:
-                _wgrad_bf16(g, xh, dw, B=B, Hs=Ho, Ws=Wo, Cp=Cout, Hl=Hi, Wl=Wi, Cg=Cin, kh=kh, kw=kw, stride=stride,
-                            pad=pad, g_is_row=True, dst_sm=taps, dst_sn=Cin * taps, dst_stap=1)
-        if has_bias and ctx.needs_input_grad[2]:
-            db = _colsum_bf16(g, B * Ho * Wo, Cout)
+        need = ctx.needs_input_grad
+        dx, dw, db = _conv_backward_bf16(xh, weight, g, stride, pad, transposed, in_dtype, tap_mask, need[0], need[1],
+                                         has_bias and need[2])
         return dx, dw, db, None, None, None, None, None, None, None, None
+
+
+def _conv_backward_bf16(xh, weight, g, stride, pad, transposed, in_dtype, tap_mask, need_dx, need_dw, need_db):
+    """input / weight / bias gradients of a bf16-storage convolution from g = dL/d(conv output), bf16 NHWC"""
+    B, Hi, Wi, Cin = xh.shape
+    _, Ho, Wo, Cout = g.shape
+    kh, kw = weight.shape[2], weight.shape[3]
+    taps = kh * kw
+    dx = dw = db = None
+    if need_dx:
+        wp = _pack_conv_weight_bf16(weight, transposed, True)
+        dxh = torch.empty((B, Hi, Wi, Cin), device=g.device, dtype=in_dtype)
+        _igemm_bf16(g, wp, dxh, B=B, Hi=Ho, Wi=Wo, Cin=Cout, Ho=Hi, Wo=Wi, Cout=Cin, kh=kh, kw=kw, stride=stride,
+                    pad=pad, transposed=not transposed, tap_mask=tap_mask)
+        dx = _nchw_view(dxh)
+    if need_dw:
+        dw = grad_like(weight)
+        if transposed:
+            _wgrad_bf16(xh, g, dw, B=B, Hs=Hi, Ws=Wi, Cp=Cin, Hl=Ho, Wl=Wo, Cg=Cout, kh=kh, kw=kw, stride=stride,
+                        pad=pad, g_is_row=False, dst_sm=Cout * taps, dst_sn=taps, dst_stap=1)
+        else:
+            _wgrad_bf16(g, xh, dw, B=B, Hs=Ho, Ws=Wo, Cp=Cout, Hl=Hi, Wl=Wi, Cg=Cin, kh=kh, kw=kw, stride=stride,
+                        pad=pad, g_is_row=True, dst_sm=taps, dst_sn=Cin * taps, dst_stap=1)
+    if need_db:
+        db = _colsum_bf16(g, B * Ho * Wo, Cout)
+    return dx, dw, db
 
 
 def _kpad8(kh, kw, c):
@@ -195,20 +204,7 @@ class _ImageConvBF16Fn(torch.autograd.Function):
         _check(x, weight, bias)
         if x.requires_grad:
             raise NotImplementedError("the bf16 stem does not produce a gradient for the image")
-        xh = _nhwc(x).float()
-        B, Hi, Wi, Cin = xh.shape
-        Cout, _, kh, kw = weight.shape
-        Ho, Wo = conv_out_size(Hi, Wi, kh, stride, pad, False)
-        Kp, P, taps = _kpad8(kh, kw, Cin), B * Ho * Wo, kh * kw
-        lib = L.load()
-        col = torch.empty((P, Kp), device=x.device, dtype=BF16)
-        L.check(lib.lic_im2col_bf16(_ptr(xh), _ptr(col), B, Hi, Wi, Cin, Ho, Wo, kh, kw, stride, pad, Kp, _stream()),
-                "lic_im2col_bf16")
-        wpk = prepared(weight, "bf16.stem")
-        if wpk is None:
-            wd = torch.zeros((Kp, Cout), device=x.device, dtype=torch.float32)
-            _permute3(weight.contiguous(), wd, (taps, Cin, Cout), (1, taps, Cin * taps), (Cin * Cout, Cout, 1))
-            wpk = _pack_bf16(wd, 1, Kp, Cout, 0, Cout, 1)
+        col, wpk, (B, Ho, Wo, Cout, Cin, Kp, P) = _stem_columns_bf16(x, weight, stride, pad)
         out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=BF16)
         _igemm_bf16(col, wpk, out, B=1, Hi=1, Wi=P, Cin=Kp, Ho=1, Wo=P, Cout=Cout,
                     kh=1, kw=1, stride=1, pad=0, transposed=False, bias=bias)
@@ -220,20 +216,43 @@ class _ImageConvBF16Fn(torch.autograd.Function):
     def backward(ctx, gy):
         col, weight = ctx.saved_tensors
         Cin, has_bias = ctx.cfg
-        g = _as_bf16_nhwc(gy)
-        B, Ho, Wo, Cout = g.shape
-        _, _, kh, kw = weight.shape
-        taps, Kp, P = kh * kw, col.shape[1], B * Ho * Wo
-        dw = db = None
-        if ctx.needs_input_grad[1]:
-            tmp = torch.empty((Kp, Cout), device=g.device, dtype=torch.float32)
-            _wgrad_bf16(col, g, tmp, B=1, Hs=1, Ws=P, Cp=Kp, Hl=1, Wl=P, Cg=Cout, kh=1, kw=1, stride=1, pad=0,
-                        g_is_row=False, dst_sm=Cout, dst_sn=1, dst_stap=0)
-            dw = grad_like(weight)
-            _permute3(tmp, dw, (taps, Cin, Cout), (Cin * Cout, Cout, 1), (1, taps, Cin * taps))
-        if has_bias and ctx.needs_input_grad[2]:
-            db = _colsum_bf16(g, P, Cout)
+        dw, db = _stem_backward_bf16(col, weight, _as_bf16_nhwc(gy), Cin, ctx.needs_input_grad[1],
+                                     has_bias and ctx.needs_input_grad[2])
         return None, dw, db, None, None
+
+
+def _stem_columns_bf16(x, weight, stride, pad):
+    """fp32 image -> bf16 columns [P][Kp] plus the packed [Kp][Cout] weight of the RGB stem"""
+    xh = _nhwc(x).float()
+    B, Hi, Wi, Cin = xh.shape
+    Cout, _, kh, kw = weight.shape
+    Ho, Wo = conv_out_size(Hi, Wi, kh, stride, pad, False)
+    Kp, P, taps = _kpad8(kh, kw, Cin), B * Ho * Wo, kh * kw
+    col = torch.empty((P, Kp), device=x.device, dtype=BF16)
+    L.check(L.load().lic_im2col_bf16(_ptr(xh), _ptr(col), B, Hi, Wi, Cin, Ho, Wo, kh, kw, stride, pad, Kp, _stream()),
+            "lic_im2col_bf16")
+    wpk = prepared(weight, "bf16.stem")
+    if wpk is None:
+        wd = torch.zeros((Kp, Cout), device=x.device, dtype=torch.float32)
+        _permute3(weight.contiguous(), wd, (taps, Cin, Cout), (1, taps, Cin * taps), (Cin * Cout, Cout, 1))
+        wpk = _pack_bf16(wd, 1, Kp, Cout, 0, Cout, 1)
+    return col, wpk, (B, Ho, Wo, Cout, Cin, Kp, P)
+
+
+def _stem_backward_bf16(col, weight, g, Cin, need_dw, need_db):
+    B, Ho, Wo, Cout = g.shape
+    _, _, kh, kw = weight.shape
+    taps, Kp, P = kh * kw, col.shape[1], B * Ho * Wo
+    dw = db = None
+    if need_dw:
+        tmp = torch.empty((Kp, Cout), device=g.device, dtype=torch.float32)
+        _wgrad_bf16(col, g, tmp, B=1, Hs=1, Ws=P, Cp=Kp, Hl=1, Wl=P, Cg=Cout, kh=1, kw=1, stride=1, pad=0,
+                    g_is_row=False, dst_sm=Cout, dst_sn=1, dst_stap=0)
+        dw = grad_like(weight)
+        _permute3(tmp, dw, (taps, Cin, Cout), (Cin * Cout, Cout, 1), (1, taps, Cin * taps))
+    if need_db:
+        db = _colsum_bf16(g, P, Cout)
+    return dw, db
 
 
 class _ImageConvTBF16Fn(torch.autograd.Function):
@@ -307,18 +326,13 @@ def _gamma_eff(gamma, gamma_bound, pedestal):
 
 class _GDNBF16Fn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, beta, gamma, inverse, beta_bound, gamma_bound, pedestal):
+    def forward(ctx, x, beta, gamma, inverse, beta_bound, gamma_bound, pedestal, keep=True):
         _check(x, beta, gamma)
-        lib = L.load()
         xh = _as_bf16_nhwc(x)
         B, H, W, Cc = xh.shape
-        beta_e, gT = prepared(beta, "f32.beta_e"), prepared(gamma, "bf16.gdn_gT")
-        if beta_e is None or gT is None:
-            beta_c = beta.contiguous()
-            beta_e = torch.empty_like(beta_c)
-            L.check(lib.lic_gdn_reparam(_ptr(beta_c), _ptr(beta_e), Cc, beta_bound, pedestal, _stream()), "lic_gdn_reparam")
-            gT = _pack_bf16(_gamma_eff(gamma, gamma_bound, pedestal), 1, Cc, Cc, 0, 1, Cc)
-        out, norm = torch.empty_like(xh), torch.empty_like(xh)
+        beta_e, gT = _gdn_operands_bf16(beta, gamma, beta_bound, gamma_bound, pedestal)
+        out = torch.empty_like(xh)
+        norm = torch.empty_like(xh) if keep else None   # (only the backward pass reads it)
         P = B * H * W
         _igemm_bf16(xh, gT, out, B=1, Hi=1, Wi=P, Cin=Cc, Ho=1, Wo=P, Cout=Cc, kh=1, kw=1, stride=1, pad=0,
                     transposed=False, bias=beta_e, prologue=1, epilogue=L.EPI_IGDN if inverse else L.EPI_GDN,
@@ -330,38 +344,158 @@ class _GDNBF16Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gy):
         xh, norm, beta, gamma = ctx.saved_tensors
-        inverse, beta_bound, gamma_bound, pedestal = ctx.cfg
-        beta_c, gamma_c = beta.contiguous(), gamma.contiguous()
-        lib = L.load()
-        g = _as_bf16_nhwc(gy)
-        B, H, W, Cc = xh.shape
-        P = B * H * W
-        t = torch.empty_like(xh)
-        L.check(lib.lic_gdn_dnorm_bf16(_ptr(g), _ptr(xh), _ptr(norm), _ptr(t), xh.numel(), int(inverse), _stream()),
-                "lic_gdn_dnorm_bf16")
-        dx = dbeta = dgamma = None
-        if ctx.needs_input_grad[0]:
-            dxh = torch.empty_like(xh)
-            gp = prepared(gamma, "bf16.gdn_g")
-            if gp is None:
-                gp = _pack_bf16(_gamma_eff(gamma, gamma_bound, pedestal), 1, Cc, Cc, 0, Cc, 1)
-            _igemm_bf16(t, gp, dxh, B=1, Hi=1, Wi=P, Cin=Cc, Ho=1, Wo=P, Cout=Cc,
-                        kh=1, kw=1, stride=1, pad=0, transposed=False,
-                        epilogue=L.EPI_IGDN_BWD if inverse else L.EPI_GDN_BWD, aux=g, aux2=xh, aux3=norm)
-            dx = _nchw_view(dxh)
-        if ctx.needs_input_grad[1]:
-            dbe = _colsum_bf16(t, P, Cc)
-            dbeta = torch.empty_like(beta_c)
-            L.check(lib.lic_gdn_reparam_bwd(_ptr(beta_c), _ptr(dbe), _ptr(dbeta), Cc, beta_bound, _stream()),
-                    "lic_gdn_reparam_bwd")
-        if ctx.needs_input_grad[2]:
-            dge = torch.empty_like(gamma_c)
-            _wgrad_bf16(t, xh, dge, B=1, Hs=1, Ws=P, Cp=Cc, Hl=1, Wl=P, Cg=Cc, kh=1, kw=1, stride=1, pad=0,
-                        g_is_row=False, dst_sm=Cc, dst_sn=1, dst_stap=0, sq_g=1)
-            dgamma = torch.empty_like(gamma_c)
-            L.check(lib.lic_gdn_reparam_bwd(_ptr(gamma_c), _ptr(dge), _ptr(dgamma), Cc * Cc, gamma_bound, _stream()),
-                    "lic_gdn_reparam_bwd")
-        return dx, dbeta, dgamma, None, None, None, None
+        need = ctx.needs_input_grad
+        dxh, dbeta, dgamma = _gdn_backward_bf16(xh, norm, beta, gamma, _as_bf16_nhwc(gy), *ctx.cfg, need[0], need[1],
+                                                need[2])
+        return (None if dxh is None else _nchw_view(dxh)), dbeta, dgamma, None, None, None, None, None
+
+
+def _gdn_operands_bf16(beta, gamma, beta_bound, gamma_bound, pedestal, kperm=False):
+    """beta_eff (fp32) and gamma_eff^T packed as the bf16 operand of the pooling contraction (`kperm`: in the K
+    order of the fused conv+GDN kernel, lic_pack_weight_bf16_kperm)"""
+    beta_e, gT = prepared(beta, "f32.beta_e"), prepared(gamma, "bf16.gdn_gTp" if kperm else "bf16.gdn_gT")
+    if beta_e is None or gT is None:
+        Cc = beta.numel()
+        beta_c = beta.contiguous()
+        beta_e = torch.empty_like(beta_c)
+        L.check(L.load().lic_gdn_reparam(_ptr(beta_c), _ptr(beta_e), Cc, beta_bound, pedestal, _stream()),
+                "lic_gdn_reparam")
+        gT = _pack_bf16(_gamma_eff(gamma, gamma_bound, pedestal), 1, Cc, Cc, 0, 1, Cc, kperm=kperm)
+    return beta_e, gT
+
+
+def _gdn_backward_bf16(xh, norm, beta, gamma, g, inverse, beta_bound, gamma_bound, pedestal, need_dx, need_dbeta,
+                       need_dgamma):
+    """gradients of y = x * norm^-1/2 (or ^1/2), norm = beta_eff + x^2 . gamma_eff^T, from g = dL/dy (bf16 NHWC);
+    dx comes back as a bf16 NHWC tensor"""
+    beta_c, gamma_c = beta.contiguous(), gamma.contiguous()
+    lib = L.load()
+    B, H, W, Cc = xh.shape
+    P = B * H * W
+    t = torch.empty_like(xh)
+    L.check(lib.lic_gdn_dnorm_bf16(_ptr(g), _ptr(xh), _ptr(norm), _ptr(t), xh.numel(), int(inverse), _stream()),
+            "lic_gdn_dnorm_bf16")
+    dxh = dbeta = dgamma = None
+    if need_dx:
+        dxh = torch.empty_like(xh)
+        gp = prepared(gamma, "bf16.gdn_g")
+        if gp is None:
+            gp = _pack_bf16(_gamma_eff(gamma, gamma_bound, pedestal), 1, Cc, Cc, 0, Cc, 1)
+        _igemm_bf16(t, gp, dxh, B=1, Hi=1, Wi=P, Cin=Cc, Ho=1, Wo=P, Cout=Cc,
+                    kh=1, kw=1, stride=1, pad=0, transposed=False,
+                    epilogue=L.EPI_IGDN_BWD if inverse else L.EPI_GDN_BWD, aux=g, aux2=xh, aux3=norm)
+    if need_dbeta:
+        dbe = _colsum_bf16(t, P, Cc)
+        dbeta = torch.empty_like(beta_c)
+        L.check(lib.lic_gdn_reparam_bwd(_ptr(beta_c), _ptr(dbe), _ptr(dbeta), Cc, beta_bound, _stream()),
+                "lic_gdn_reparam_bwd")
+    if need_dgamma:
+        dge = torch.empty_like(gamma_c)
+        _wgrad_bf16(t, xh, dge, B=1, Hs=1, Ws=P, Cp=Cc, Hl=1, Wl=P, Cg=Cc, kh=1, kw=1, stride=1, pad=0,
+                    g_is_row=False, dst_sm=Cc, dst_sn=1, dst_stap=0, sq_g=1)
+        dgamma = torch.empty_like(gamma_c)
+        L.check(lib.lic_gdn_reparam_bwd(_ptr(gamma_c), _ptr(dge), _ptr(dgamma), Cc * Cc, gamma_bound, _stream()),
+                "lic_gdn_reparam_bwd")
+    return dxh, dbeta, dgamma
+
+
+class _ConvGDNBF16Fn(torch.autograd.Function):
+    """conv / transposed conv -> GDN / IGDN (Components.py:10-15, 39-44) as ONE launch in bf16 storage
+    (LIC_EPI_CONV_GDN of lic_igemm_bf16).  Same rounding points as conv2d_bf16 -> gdn_bf16 (the conv output is
+    bitwise the same; the pool sums every 16 channels in another order, so norm and y agree to fp32 / one-bf16-ulp
+    rounding); the convolution output and the norm are written only when a backward pass will need them."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, beta, gamma, stride, pad, out_pad, transposed, inverse, beta_bound,
+                gamma_bound, pedestal, keep):
+        _check(x, weight, bias, beta, gamma)
+        stem = (not transposed) and weight.shape[1] < 4
+        beta_e, gT = _gdn_operands_bf16(beta, gamma, beta_bound, gamma_bound, pedestal, kperm=True)
+        kh, kw = weight.shape[2], weight.shape[3]
+        epi = L.EPI_CONV_IGDN if inverse else L.EPI_CONV_GDN
+        direct = False
+        if stem:
+            if x.requires_grad:
+                raise NotImplementedError("the bf16 stem does not produce a gradient for the image")
+            direct = bool(L.load().lic_stem_gdn_bf16_supported(weight.shape[1], weight.shape[0], kh, kw, stride, pad))
+        if direct:
+            # image -> normalised features in one launch, no column matrix (lic_stem_gdn_bf16); the backward pass
+            # builds the columns its weight gradient needs from the saved image
+            lib = L.load()
+            src = _nhwc(x).float()
+            B, Hi, Wi, Cin = src.shape
+            Cout = weight.shape[0]
+            Ho, Wo = conv_out_size(Hi, Wi, kh, stride, pad, False)
+            wp = prepared(weight, "bf16.stem16")
+            if wp is None:
+                wp = torch.empty((lib.lic_stem_weight_bf16_elems(Cout),), device=x.device, dtype=BF16)
+                L.check(lib.lic_pack_stem_weight_bf16(_ptr(weight.contiguous()), _ptr(wp), Cout, _stream()),
+                        "lic_pack_stem_weight_bf16")
+            y = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=BF16)
+            conv_out = torch.empty_like(y) if keep else None
+            norm = torch.empty_like(y) if keep else None
+            from . import functional as F_
+            if F_.KERNEL_TRACE is not None:
+                F_.KERNEL_TRACE.add(f"stem_gdn_bf16_kernel<{Cout // 32}, {8 if Cout == 192 else 4}>")
+            L.check(lib.lic_stem_gdn_bf16(_ptr(src), _ptr(wp), _ptr(bias), _ptr(gT), _ptr(beta_e), _ptr(y), _ptr(conv_out),
+                                          _ptr(norm), B, Hi, Wi, Cout, int(inverse), _stream()), "lic_stem_gdn_bf16")
+        else:
+            if stem:
+                src, wp, (B, Ho, Wo, Cout, Cin, Kp, P) = _stem_columns_bf16(x, weight, stride, pad)
+                geo = dict(B=1, Hi=1, Wi=P, Cin=Kp, Ho=1, Wo=P, Cout=Cout, kh=1, kw=1, stride=1, pad=0, transposed=False)
+            else:
+                src = _as_bf16_nhwc(x)
+                B, Hi, Wi, Cin = src.shape
+                Cout = weight.shape[1] if transposed else weight.shape[0]
+                Ho, Wo = conv_out_size(Hi, Wi, kh, stride, pad, transposed, out_pad)
+                wp = _pack_conv_weight_bf16(weight, transposed, False)
+                geo = dict(B=B, Hi=Hi, Wi=Wi, Cin=Cin, Ho=Ho, Wo=Wo, Cout=Cout, kh=kh, kw=kw, stride=stride, pad=pad,
+                           transposed=transposed)
+            y = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=BF16)
+            conv_out = torch.empty_like(y) if keep else None
+            norm = torch.empty_like(y) if keep else None
+            _igemm_bf16(src, wp, y, bias=bias, epilogue=epi, aux=gT, aux2=beta_e, out2=norm, out3=conv_out, **geo)
+        ctx.save_for_backward(src, weight, conv_out, norm, beta, gamma)
+        ctx.cfg = (stride, pad, transposed, inverse, beta_bound, gamma_bound, pedestal, bias is not None, x.dtype, stem,
+                   Cin, direct)
+        return _nchw_view(y)
+
+    @staticmethod
+    def backward(ctx, gy):
+        src, weight, conv_out, norm, beta, gamma = ctx.saved_tensors
+        (stride, pad, transposed, inverse, beta_bound, gamma_bound, pedestal, has_bias, in_dtype, stem, Cin,
+         direct) = ctx.cfg
+        need = ctx.needs_input_grad
+        g_conv, dbeta, dgamma = _gdn_backward_bf16(conv_out, norm, beta, gamma, _as_bf16_nhwc(gy), inverse, beta_bound,
+                                                   gamma_bound, pedestal, True, need[3], need[4])
+        if direct and (need[1] or (has_bias and need[2])):   # src is the image: its columns for the weight gradient
+            src = _stem_columns_bf16(_nchw_view(src), weight, stride, pad)[0]
+        if stem:
+            dx = None
+            dw, db = _stem_backward_bf16(src, weight, g_conv, Cin, need[1], has_bias and need[2])
+        else:
+            dx, dw, db = _conv_backward_bf16(src, weight, g_conv, stride, pad, transposed, in_dtype, 0, need[0], need[1],
+                                             has_bias and need[2])
+        return dx, dw, db, dbeta, dgamma, None, None, None, None, None, None, None, None, None
+
+
+def _will_backprop(*ts):
+    """True when autograd will record the op being built (inside Function.forward grad mode is always off and
+    needs_input_grad ignores torch.no_grad(), so the wrappers ask before .apply): tensors that only the backward
+    pass reads are written only then"""
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
+
+
+def fused_gdn_supported_bf16(cin: int, cout: int) -> bool:
+    return bool(L.load().lic_igemm_bf16_fused_gdn_supported(int(cin), int(cout)))
+
+
+def conv_gdn_bf16(x, weight, bias, beta, gamma, stride, padding, inverse, beta_bound, gamma_bound, pedestal=PEDESTAL,
+                  transposed=False, output_padding=0):
+    """`gdn_bf16(conv2d_bf16(x))` / `gdn_bf16(conv_transpose2d_bf16(x))` in one launch (see _ConvGDNBF16Fn)"""
+    return _ConvGDNBF16Fn.apply(x, weight, bias, beta, gamma, stride, padding, output_padding, bool(transposed),
+                                bool(inverse), float(beta_bound), float(gamma_bound), float(pedestal),
+                                _will_backprop(x, weight, bias, beta, gamma))
 
 
 def conv2d_bf16(x, weight, bias, stride, padding, out_f32=False, leaky=False, slope=0.01, tap_mask=0):
@@ -381,4 +515,5 @@ def image_conv_transpose2d_bf16(x, weight, bias, stride, padding, output_padding
 
 
 def gdn_bf16(x, beta, gamma, inverse, beta_bound, gamma_bound, pedestal=PEDESTAL):
-    return _GDNBF16Fn.apply(x, beta, gamma, bool(inverse), float(beta_bound), float(gamma_bound), float(pedestal))
+    return _GDNBF16Fn.apply(x, beta, gamma, bool(inverse), float(beta_bound), float(gamma_bound), float(pedestal),
+                            _will_backprop(x, beta, gamma))

@@ -92,6 +92,16 @@ def run_bf16(seq: nn.Sequential, x: Tensor, out_f32: bool = True) -> Tensor:
                 x = m(x, bf16=True, leaky=True, slope=nxt.negative_slope)
                 i += 2
                 continue
+            if FUSE_CONV_GDN and isinstance(nxt, GDN) and m.groups == 1 and _pair(m.dilation) == 1 and x.dim() == 4 and \
+                    (isinstance(m, Conv2d) or m.out_channels >= 4) and \
+                    FB_.fused_gdn_supported_bf16(max(m.in_channels, 8), m.out_channels):
+                tr = isinstance(m, ConvTranspose2d)
+                x = FB_.conv_gdn_bf16(x, m.weight, m.bias, nxt.beta, nxt.gamma, _pair(m.stride), _pair(m.padding),
+                                     nxt.inverse, nxt.beta_reparam.bound_value, nxt.gamma_reparam.bound_value,
+                                     nxt.beta_reparam.pedestal_value, transposed=tr,
+                                     output_padding=_pair(m.output_padding) if tr else 0)
+                i += 2
+                continue
             x = m(x, bf16=True, out_f32=(out_f32 and i == len(mods) - 1))
         elif isinstance(m, GDN):
             x = m(x, bf16=True)

@@ -20,7 +20,7 @@ import torch
 
 from . import _lib as L
 from . import functional as F_
-from .layers import Conv2d, ConvTranspose2d, GDN
+from .layers import Conv2d, ConvTranspose2d, GDN, _pair
 
 BF16 = torch.bfloat16
 # sub-modules of the models that carry a `precision` attribute (models.set_precision)
@@ -85,13 +85,13 @@ class StepPrep:
             j.transform, j.bound, j.pedestal = transform, bound, pedestal
             jobs.append(j)
 
-        def pack(param, kind_name, half, **kw):
+        def pack(param, kind_name, half, kperm=False, **kw):
             taps, K, N = kw.get("taps", 1), kw["K"], kw["N"]
             if half:
                 dst = torch.empty((lib.lic_packed_weight_bf16_elems(taps, K, N),), device=dev, dtype=BF16)
             else:
                 dst = torch.empty((lib.lic_packed_weight_floats(taps, K, N),), device=dev, dtype=torch.float32)
-            job(L.PREP_PACK_BF16 if half else L.PREP_PACK_F32, param, dst, **kw)
+            job((L.PREP_PACK_BF16_KPERM if kperm else L.PREP_PACK_BF16) if half else L.PREP_PACK_F32, param, dst, **kw)
             entries.append((param, ("bf16." if half else "f32.") + kind_name, dst))
 
         for m in self.model.modules():
@@ -104,6 +104,8 @@ class StepPrep:
                 entries.append((m.beta, "f32.beta_e", beta_e))
                 gkw = dict(K=Cc, N=Cc, transform=1, bound=m.gamma_reparam.bound_value, pedestal=ped)
                 pack(m.gamma, "gdn_gT", half, s_k=1, s_n=Cc, **gkw)     # B operand [k = j][n = i] = gamma_eff[i][j]
+                if half:   # the same operand in the K order of the one-launch conv+GDN kernel
+                    pack(m.gamma, "gdn_gTp", True, kperm=True, s_k=1, s_n=Cc, **gkw)
                 pack(m.gamma, "gdn_g", half, s_k=Cc, s_n=1, **gkw)      # backward: t . gamma_eff
                 params += [m.beta, m.gamma]
             elif isinstance(m, (Conv2d, ConvTranspose2d)):
@@ -121,6 +123,11 @@ class StepPrep:
                     entries.append((w, "masked", w))
                 if not tr and cin < 4:      # RGB stem: dense [taps*Cin][Cout] column matrix
                     pack(w, "stem", half, K=taps * cin, N=cout, kdiv=cin, s_k=1, s_kr=taps, s_n=cin * taps, mask=mask)
+                    if half and mask is None and lib.lic_stem_gdn_bf16_supported(cin, cout, kh, kw_, _pair(m.stride),
+                                                                                 _pair(m.padding)):
+                        dst = torch.empty((lib.lic_stem_weight_bf16_elems(cout),), device=dev, dtype=BF16)
+                        job(L.PREP_PACK_BF16_STEM, w, dst, N=cout)     # operand of the one-launch stem + GDN
+                        entries.append((w, "bf16.stem16", dst))
                 elif tr and cout < 4:       # RGB head: [Cin][taps*Cout] and its transpose for the data gradient
                     pack(w, "head", half, K=cin, N=taps * cout, s_k=cout * taps, ndiv=cout, s_n=1, s_nr=taps)
                     pack(w, "head_dx", half, K=taps * cout, N=cin, kdiv=cout, s_k=1, s_kr=taps, s_n=cout * taps)

@@ -156,6 +156,86 @@ def test_gdn_bf16(env, inverse):
     scale_close(host(m.gamma.grad), O.gdn_reparam_bwd(gamma_p, dge, 0.0), 3e-2, "dgamma")
 
 
+# conv -> GDN in one launch (LIC_EPI_CONV_GDN of lic_igemm_bf16): every N tile, ragged M, the 4-phase transposed
+# gather and the RGB stem, against the two-launch path.  Same rounding points (x and x^2 to bf16, fp32 norm); the
+# fused pool sums each group of 16 channels in another order, so: y within one bf16 rounding, gradients (which see
+# the occasional 1-ulp flip of the stored bf16 norm) within 1 % of their scale -- and, through the two-launch path,
+# the oracle tolerances of the tests above
+@pytest.mark.parametrize("k,s,p,ci,co,H,W,B,tr,op,inverse,bm", [
+    (5, 2, 2, 64, 64, 11, 9, 2, False, 0, False, 64),     # 64-column tile, ragged rows
+    (5, 2, 2, 64, 128, 16, 16, 2, False, 0, False, 128),  # 128x128 tile
+    (5, 2, 2, 128, 128, 9, 7, 3, False, 0, False, 64),
+    (3, 1, 1, 72, 192, 8, 8, 2, False, 0, False, 128),    # 192-column tile, K tail (72 = 2 chunks + 8)
+    (5, 2, 2, 128, 192, 7, 5, 2, True, 1, True, 64),      # transposed, 4 phases, IGDN
+    (5, 2, 2, 64, 128, 8, 8, 2, True, 1, True, 128),
+    (5, 2, 2, 3, 128, 20, 18, 2, False, 0, False, 128),   # RGB stem: image -> features in one launch (lic_stem_gdn_bf16)
+    (5, 2, 2, 3, 192, 12, 12, 1, False, 0, False, 64),
+    (5, 2, 2, 3, 64, 21, 19, 3, False, 0, False, 64),     # odd sizes: every border case of the window loads
+    (5, 2, 2, 3, 128, 96, 80, 3, False, 0, False, 128),   # 45 tiles: the persistent loop
+    (3, 2, 1, 3, 128, 12, 12, 2, False, 0, False, 128),   # a stem the direct kernel does not cover: columns + GEMM
+])
+def test_conv_gdn_fused_bf16_matches_two_launches(env, k, s, p, ci, co, H, W, B, tr, op, inverse, bm):
+    nic, FB, O, d = env
+    from neural_image_compression_amd import functional as F_
+    from neural_image_compression_amd.layers import GDN
+    r = np.random.RandomState(11)
+    x = rb(r.randn(B, ci, H, W).astype(np.float32))
+    wshape = (ci, co, k, k) if tr else (co, ci, k, k)
+    w = torch.from_numpy(rb(r.randn(*wshape).astype(np.float32) / math.sqrt(ci * k * k))).to(d).requires_grad_(True)
+    b = torch.from_numpy(rb(0.1 * r.randn(co).astype(np.float32))).to(d).requires_grad_(True)
+    g = GDN(co, inverse=inverse).to(d)
+    with torch.no_grad():
+        g.beta.copy_(torch.from_numpy(R.make_param("g.beta", (co,), 3)))
+        g.gamma.copy_(torch.from_numpy(R.make_param("g.gamma", (co, co), 3)))
+    bb, gb, pd = g.beta_reparam.bound_value, g.gamma_reparam.bound_value, g.beta_reparam.pedestal_value
+    stem = ci < 4
+    x_dtype = None if stem else BF
+
+    def two(xin):
+        if stem:
+            c = FB.image_conv2d_bf16(xin, w, b, s, p)
+        elif tr:
+            c = FB.conv_transpose2d_bf16(xin, w, b, s, p, op)
+        else:
+            c = FB.conv2d_bf16(xin, w, b, s, p)
+        return FB.gdn_bf16(c, g.beta, g.gamma, inverse, bb, gb, pd)
+
+    def one(xin):
+        return FB.conv_gdn_bf16(xin, w, b, g.beta, g.gamma, s, p, inverse, bb, gb, pd, transposed=tr, output_padding=op)
+
+    F_.FORCE_IGEMM = (bm, 0, 0)
+    try:
+        names = set()
+        F_.KERNEL_TRACE = names
+        res = []
+        for fn in (two, one):
+            for t in (w, b, g.beta, g.gamma):
+                t.grad = None
+            tx = dev(x, d, x_dtype, grad=not stem)
+            y = fn(tx)
+            dy = dev(rb(np.random.RandomState(12).randn(*y.shape).astype(np.float32)), d, BF)
+            y.backward(dy)
+            res.append([host(y)] + ([] if stem else [host(tx.grad)]) + [host(t.grad) for t in (w, b, g.beta, g.gamma)])
+        with torch.no_grad():   # inference: nothing but y is written
+            y_inf = host(one(dev(x, d, x_dtype)))
+    finally:
+        F_.FORCE_IGEMM = None
+        F_.KERNEL_TRACE = None
+    tn = co // 64
+    if stem and (k, s, p) == (5, 2, 2):
+        assert f"stem_gdn_bf16_kernel<{co // 32}, {8 if co == 192 else 4}>" in names, names
+    else:
+        assert f"igemm_bf16_kernel<128, {tn}, false, true>" in names, names
+    whats = ["y"] + ([] if stem else ["dx"]) + ["dw", "db", "dbeta", "dgamma"]
+    # y: at most one bf16 ulp apart (an ulp is 2^-8 .. 2^-7 of the value); the direct stem also sums its 75 products
+    # in another order than the column GEMM, so its conv output can itself sit one ulp away
+    ya, yb = np.asarray(res[1][0], np.float64), np.asarray(res[0][0], np.float64)
+    assert (np.abs(ya - yb) <= 2.0 ** -7 * np.abs(yb) + 2.0 ** -8 * 1e-2 * np.abs(yb).max()).all(), np.abs(ya - yb).max()
+    assert (ya != yb).mean() < 0.05      # ... and only here and there
+    for a, bq, what in zip(res[0][1:], res[1][1:], whats[1:]):
+        scale_close(bq, a, 1e-2, f"{what} (fused vs conv -> gdn)")
+    assert np.array_equal(y_inf, res[1][0])   # inference (y only) == training forward
+
 @pytest.mark.parametrize("M,K,B", [(64, 3, 2), (128, 3, 2)])
 def test_model_bf16_vs_fp32(env, M, K, B):
     """Config 3's model (JAH, K=3) in bf16 mode against the same weights in fp32 mode."""
