@@ -265,6 +265,10 @@ int64_t lic_packed_weight_bf16_elems(int32_t taps, int32_t K, int32_t N);
 int lic_pack_weight_bf16(const float* src, void* dst, int32_t taps, int32_t K, int32_t N, int64_t s_tap,
                          int64_t s_k, int64_t s_n, lic_stream_t stream);
 int lic_igemm_bf16(const lic_igemm_desc* d, int32_t out_f32, lic_stream_t stream);
+/* workspace size that lets lic_igemm_bf16 split K across workgroups for `d` (0 = large enough not to need it);
+ * pass the buffer in d->workspace / workspace_bytes.  The split is a function of per-image geometry only.
+ * force_split of the descriptor is honoured (1 = never, n > 1 = n splits). */
+size_t lic_igemm_bf16_workspace_bytes(const lic_igemm_desc* d);
 /* lic_igemm_bf16 also runs LIC_EPI_CONV_GDN / LIC_EPI_CONV_IGDN (the conv -> GDN pairs of Components.py:10-15,
  * 39-44 in one launch) when this returns 1 (Cout in {64,128,192}: one tile spans every output channel; bf16 `out`):
  * aux = gamma_eff^T packed by lic_pack_weight_bf16_kperm(taps=1, K=Cout, N=Cout), aux2 = beta_eff (fp32 [Cout]),

@@ -98,6 +98,7 @@ SIGNATURES = {
     "lic_pack_weight_bf16_kperm": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i64, _i64, _i64, _vp]),
     "lic_igemm_bf16": (C.c_int, [C.POINTER(IgemmDesc), _i32, _vp]),
     "lic_igemm_bf16_kernel_name": (C.c_int, [C.POINTER(IgemmDesc), C.c_char_p, _sz]),
+    "lic_igemm_bf16_workspace_bytes": (_sz, [C.POINTER(IgemmDesc)]),
     "lic_igemm_bf16_fused_gdn_supported": (C.c_int, [_i32, _i32]),
     "lic_stem_gdn_bf16_supported": (C.c_int, [_i32] * 6),
     "lic_stem_weight_bf16_elems": (C.c_int64, [_i32]),

@@ -49,6 +49,8 @@ struct IgemmHParams {
   int kw, stride, pad, transposed, prologue, epilogue, out_f32;
   float slope;  // LIC_EPI_LEAKY
   int cpt, Npad, nphase, MT, NT;
+  int ksplit, cps;  // K split across workgroups (1 = none): chunks per split; fp32 partial tiles go to `slabs`
+  float* slabs;     // [ksplit][B*Ho*Wo][Cout]
   int pgroup, porder;  // 4-phase launches: phase-sorted groups of `pgroup` M tiles, order 2 bits per rank
   int ntaps[4];
   int Hq[4], Wq[4];
@@ -105,6 +107,11 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
   {
     const int q = nwg >> 3, r = nwg & 7, xcd = wg & 7, idx = wg >> 3;
     wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  int ksp = 0;
+  if (p.ksplit > 1) {  // the splits of a tile are neighbours in launch order (they share its activations in L2)
+    ksp = wg % p.ksplit;
+    wg /= p.ksplit;
   }
   const int nt = wg % p.NT;
   const int kq = wg / p.NT;
@@ -175,7 +182,9 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
     s_taps[tid] = tt | (tr << 8) | ((tt - tr * p.kw) << 16);
   }
   __syncthreads();
-  const int nchunks = ntaps * p.cpt;
+  const int nch_all = ntaps * p.cpt;
+  const int c_lo = ksp * p.cps < nch_all ? ksp * p.cps : nch_all;                       // this split's chunks
+  const int nchunks = (p.ksplit > 1 ? (c_lo + p.cps < nch_all ? p.cps : nch_all - c_lo) : nch_all);
   const int sgn = p.transposed ? -1 : 1;
   const int sh = (p.transposed && p.stride == 2) ? 1 : 0;
   const int last_tap = ntaps - 1, last_cb = p.cpt - 1;
@@ -185,12 +194,12 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
   // full address computation (~70 VALU) per chunk would cost as much as the matrix work itself.
   long t_off[APASS];
   bool t_ok[APASS];
-  int t_tap = 0;
+  int t_tap = -1;
   auto issue = [&](int tapi, int cb, auto bufc) {
     constexpr int buf = decltype(bufc)::value;
     const bool past = tapi > last_tap;  // cursor ran past the end: harmless duplicate DMA into the idle buffer
     const int cbb = past ? last_cb : cb;
-    if (cb == 0 && !past) {  // wave-uniform: a new tap begins
+    if ((cb == 0 || t_tap < 0) && !past) {  // wave-uniform: a new tap begins (or a split starts inside one)
       const int code = __builtin_amdgcn_readfirstlane(s_taps[tapi]);
       const int r = (code >> 8) & 0xFF, s = code >> 16;
       t_tap = code & 0xFF;
@@ -202,7 +211,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
         t_off[j] = t_ok[j] ? (long)(a_base[j] + ih * p.Wi + iw) * p.in_ld : 0L;
       }
     }
-    const int tap = t_tap;
+    const int tap = t_tap < 0 ? 0 : t_tap;
     const int ci = cbb * HB_BK + gq;
     const bool cok = ci < p.Cin;
     bf16_t* dstA = bufp(buf);
@@ -251,7 +260,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
         }
   };
 
-  int l_tap = 0, l_cb = 0;
+  int l_tap = c_lo / p.cpt, l_cb = c_lo - (c_lo / p.cpt) * p.cpt;
   auto advance = [&]() {
     if (++l_cb == p.cpt) {
       l_cb = 0;
@@ -291,7 +300,12 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
 
   // ---- epilogue: stage each 32x32 fp32 tile through LDS; a lane then owns 8 consecutive
   // channels of a row (16-byte bf16 accesses; fp32 output writes two 16-byte halves) ------------
-  const int epi = p.epilogue;
+  const bool split = p.ksplit > 1;  // partial sums: raw fp32 to this split's slab, lic_igemm_bf16 finishes them
+  const int epi = split ? (int)LIC_EPI_NONE : p.epilogue;
+  const float* biasp = split ? nullptr : p.bias;
+  void* const outp = split ? (void*)(p.slabs + (long)ksp * ((long)p.B * p.Ho * p.Wo) * p.Cout) : p.out;
+  const long out_ld = split ? (long)p.Cout : p.out_ld;
+  const bool of32 = split || p.out_f32;
   float* stg = reinterpret_cast<float*>(smem_all) + wave * 1024;
   const int c8 = (lane & 3) * 8, r16 = lane >> 2;
   if constexpr (FUSE) {
@@ -403,7 +417,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
       if (col >= p.Cout) continue;
       float bias8[8];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) bias8[e] = p.bias ? p.bias[col + e] : 0.0f;
+      for (int e = 0; e < 8; ++e) bias8[e] = biasp ? biasp[col + e] : 0.0f;
 #pragma unroll
       for (int it = 0; it < 2; ++it) {
         const int rr = it * 16 + r16;
@@ -451,8 +465,8 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
             v[e] = (float)g[e] * f + 2.0f * (float)x[e] * v[e];
           }
         }
-        if (p.out_f32) {
-          float* o = reinterpret_cast<float*>(p.out) + opix * p.out_ld + col;
+        if (of32) {
+          float* o = reinterpret_cast<float*>(outp) + opix * out_ld + col;
           f32x4 o0, o1;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -465,10 +479,51 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
           bf16x8 ob;
 #pragma unroll
           for (int e = 0; e < 8; ++e) ob[e] = (bf16_t)v[e];
-          *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(p.out) + opix * p.out_ld + col) = ob;
+          *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(outp) + opix * out_ld + col) = ob;
         }
       }
     }
+}
+
+// out = epilogue(sum of the K-split slabs in slab order + bias), 8 channels per thread (C % 8 == 0)
+__global__ __launch_bounds__(256) void igemm_bf16_finish_kernel(const float* slabs, int ksplit, long npix, int C8,
+                                                               const float* bias, void* out, long out_ld, int out_f32,
+                                                               int leaky, float slope) {
+  const long total8 = npix * C8, total = total8 * 8;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total8; i += (long)gridDim.x * 256) {
+    const long pix = i / C8;
+    const int c = (int)(i - pix * C8) * 8;
+    const float* sp = slabs + i * 8;
+    f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < ksplit; ++s) {
+      v0 += *reinterpret_cast<const f32x4*>(sp + (long)s * total);
+      v1 += *reinterpret_cast<const f32x4*>(sp + (long)s * total + 4);
+    }
+    if (bias) {
+      v0 += *reinterpret_cast<const f32x4*>(bias + c);
+      v1 += *reinterpret_cast<const f32x4*>(bias + c + 4);
+    }
+    if (leaky) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v0[e] = v0[e] > 0.0f ? v0[e] : v0[e] * slope;
+        v1[e] = v1[e] > 0.0f ? v1[e] : v1[e] * slope;
+      }
+    }
+    if (out_f32) {
+      float* o = reinterpret_cast<float*>(out) + pix * out_ld + c;
+      *reinterpret_cast<f32x4*>(o) = v0;
+      *reinterpret_cast<f32x4*>(o + 4) = v1;
+    } else {
+      bf16x8 ob;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        ob[e] = (bf16_t)v0[e];
+        ob[4 + e] = (bf16_t)v1[e];
+      }
+      *reinterpret_cast<bf16x8*>(reinterpret_cast<bf16_t*>(out) + pix * out_ld + c) = ob;
+    }
+  }
 }
 
 static bool al16h(const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
@@ -642,8 +697,61 @@ static int igemmh_prepare(const lic_igemm_desc* d, int32_t out_f32, IgemmHParams
     p.MT = ((p.MT + 63) / 64) * 64;
   }
   nwg = (long)p.MT * p.NT * p.nphase;
+  // K split for layers far too small to fill the chip: the two 5x5 stride-2 layers of the hyper encoder
+  // (Components.py:71-73) are 32 and 8 workgroups of 100 chunks each -- one latency-bound K loop per CU, 32 us
+  // apiece; split 12 ways they take 12.5 + 5 us (partial fp32 tiles + igemm_bf16_finish_kernel).  Only where the
+  // gain clearly exceeds the extra launch (measured: at 128 workgroups -- the last analysis layer, the 3x3 hyper
+  // layer -- 33 -> 25 us and 15 -> 17 us).  A function of per-image geometry only, like lic_igemm's: the batch an
+  // image is computed in does not change its bits.
+  p.ksplit = 1;
+  p.cps = 0;
+  p.slabs = nullptr;
+  {
+    int max_chunks = 0;
+    for (int ph = 0; ph < p.nphase; ++ph) max_chunks = p.ntaps[ph] * p.cpt > max_chunks ? p.ntaps[ph] * p.cpt : max_chunks;
+    const bool simple = (epi == LIC_EPI_NONE || epi == LIC_EPI_LEAKY) && !d->out2 && d->prologue == 0;
+    const long t_img = (((long)d->Ho * d->Wo + 63) / 64) * (p.Npad / 64);
+    long S = 1;
+    if (simple && d->workspace && d->force_split != 1 && ((t_img < 4 && max_chunks >= 48) || d->force_split > 1) &&
+        max_chunks >= 2) {
+      S = (24 + t_img - 1) / t_img;
+      if (S > max_chunks / 8) S = max_chunks / 8;  // at least 8 chunks (256 K) per split
+      if (S > 32) S = 32;
+      if (d->force_split > 1) S = d->force_split < max_chunks ? d->force_split : max_chunks;
+    }
+    if (S > 1) {
+      p.cps = (int)((max_chunks + S - 1) / S);
+      p.ksplit = (max_chunks + p.cps - 1) / p.cps;
+      if (p.ksplit > 1) {
+        const size_t need = (size_t)p.ksplit * d->B * d->Ho * d->Wo * d->Cout * sizeof(float);
+        if (d->workspace_bytes < need || !al16h(d->workspace)) return LIC_ERR_WORKSPACE;
+        p.slabs = (float*)d->workspace;
+        nwg *= p.ksplit;
+      } else {
+        p.ksplit = 1;
+      }
+    }
+  }
   if (nwg > 0x7FFFFFFFL) return LIC_ERR_UNSUPPORTED;
   return LIC_OK;
+}
+
+LIC_EXPORT size_t lic_igemm_bf16_workspace_bytes(const lic_igemm_desc* d) {
+  if (!d) return 0;
+  lic_igemm_desc q = *d;  // plan with stand-in pointers and an unlimited workspace
+  static float dummy[4] __attribute__((aligned(16)));
+  q.in = q.w = dummy;
+  q.out = dummy;
+  q.bias = q.aux = q.aux2 = q.aux3 = q.res = nullptr;
+  q.out2 = q.out3 = nullptr;
+  if (q.epilogue != LIC_EPI_NONE && q.epilogue != LIC_EPI_LEAKY) return 0;
+  q.workspace = dummy;
+  q.workspace_bytes = ~(size_t)0;
+  IgemmHParams p;
+  int bm = 0, tn = 0;
+  long nwg = 0;
+  if (igemmh_prepare(&q, 0, p, bm, tn, nwg) != LIC_OK || p.ksplit <= 1) return 0;
+  return (size_t)p.ksplit * d->B * d->Ho * d->Wo * d->Cout * sizeof(float);
 }
 
 LIC_EXPORT int lic_igemm_bf16_kernel_name(const lic_igemm_desc* d, char* buf, size_t n) {
@@ -691,6 +799,12 @@ LIC_EXPORT int lic_igemm_bf16(const lic_igemm_desc* d, int32_t out_f32, lic_stre
   else
     LIC_IGEMMH_LAUNCH(64, 1);
 #undef LIC_IGEMMH_LAUNCH
+  if (p.ksplit > 1) {
+    const long npix = (long)d->B * d->Ho * d->Wo;
+    hipLaunchKernelGGL(igemm_bf16_finish_kernel, dim3(ew_grid(npix * d->Cout / 8, 256)), dim3(256), 0, s,
+                       (const float*)p.slabs, p.ksplit, npix, d->Cout / 8, d->bias, d->out, (long)d->out_ld,
+                       out_f32 ? 1 : 0, d->epilogue == LIC_EPI_LEAKY ? 1 : 0, d->slope);
+  }
   return lic_check_launch();
 }
 

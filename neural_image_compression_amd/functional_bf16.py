@@ -17,6 +17,7 @@ from .functional import (PEDESTAL, _colsum, _nchw_view, _nhwc, _permute3, _ptr, 
                          prepared)
 
 BF16 = torch.bfloat16
+_SPLIT_WS = {}   # geometry -> K-split workspace bytes of lic_igemm_bf16 (0 = no split)
 
 
 def _check(*ts):
@@ -70,6 +71,18 @@ def _igemm_bf16(inp, w_packed, out, *, B, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, str
     from . import functional as F_
     if F_.FORCE_IGEMM is not None:
         d.force_bm = F_.FORCE_IGEMM[0]  # the N tile follows from the channel count on this path
+        d.force_split = F_.FORCE_IGEMM[2]
+    if epilogue in (L.EPI_NONE, L.EPI_LEAKY) and prologue == 0 and out2 is None and \
+            (Ho * Wo <= 192 or d.force_split > 1):
+        # layers far too small to fill the chip split K across workgroups (fp32 partial tiles + a finishing launch);
+        # the plan depends on the geometry only, so its workspace size is asked once per shape
+        key = (B, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, pad, bool(transposed), tap_mask, d.force_split)
+        nbytes = _SPLIT_WS.get(key)
+        if nbytes is None:
+            nbytes = _SPLIT_WS[key] = L.load().lic_igemm_bf16_workspace_bytes(C.byref(d))
+        if nbytes:
+            ws = torch.empty((nbytes // 4,), device=out.device, dtype=torch.float32)
+            d.workspace, d.workspace_bytes = _ptr(ws), nbytes
     if F_.KERNEL_TRACE is not None:
         F_.KERNEL_TRACE.add(F_._kernel_name(L.load().lic_igemm_bf16_kernel_name, d))
     if F_.PROFILE is None or 2.0 * B * Ho * Wo * Cout * Cin * kh * kw < F_.PROFILE_MIN_FLOP:

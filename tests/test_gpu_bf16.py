@@ -68,7 +68,31 @@ def bf16_close(a, b, what):
                                                      (5, 2, 2, 64, 64, 6, 6, 2, True, 1),
                                                      (5, 2, 2, 192, 32, 5, 3, 1, True, 1),
                                                      (1, 1, 0, 192, 80, 4, 6, 2, False, 0)])
-def test_conv_bf16_ops(env, k, s, p, ci, co, H, W, B, tr, op):
+@pytest.mark.parametrize("split", [0, 1, 3])   # K split across workgroups: automatic (these sizes split), never, 3 ways
+def test_conv_bf16_ops(env, k, s, p, ci, co, H, W, B, tr, op, split):
+    nic, FB, O, d = env
+    from neural_image_compression_amd import functional as F_
+    F_.FORCE_IGEMM = (0, 0, split)
+    try:
+        _conv_bf16_ops(env, k, s, p, ci, co, H, W, B, tr, op)
+    finally:
+        F_.FORCE_IGEMM = None
+
+
+def test_conv_bf16_split_is_batch_invariant(env):
+    """the K split is chosen from per-image geometry: an image's output bits do not depend on its batch"""
+    nic, FB, O, d = env
+    r = np.random.RandomState(3)
+    x = dev(rb(r.randn(6, 128, 8, 8).astype(np.float32)), d, BF)
+    w = dev(rb((r.randn(128, 128, 5, 5) / 56.0).astype(np.float32)), d).contiguous()
+    b = dev(r.randn(128).astype(np.float32), d)
+    with torch.no_grad():
+        y6 = FB.conv2d_bf16(x, w, b, 2, 2)
+        y2 = FB.conv2d_bf16(x[2:4].contiguous(memory_format=torch.channels_last), w, b, 2, 2)
+    assert torch.equal(y6[2:4], y2)
+
+
+def _conv_bf16_ops(env, k, s, p, ci, co, H, W, B, tr, op):
     nic, FB, O, d = env
     r = np.random.RandomState(ci + co)
     x = rb(r.randn(B, ci, H, W).astype(np.float32))
