@@ -25,7 +25,8 @@ def main():
     model = (nic.HierarchicalMixtureResidual if kind == "hmr" else nic.JointAutoregressiveHierarchical)(M, K).to(dev)
     if cfg in bench.BF16_CONFIGS:
         model.set_precision("bf16")
-    opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+    model.overlap_branches = True
+    opt = nic.FusedAdam(model.parameters(), lr=1e-4)
     g = torch.Generator(device="cpu").manual_seed(1234)
     x = torch.rand(B, 3, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
 
