@@ -281,10 +281,11 @@ def main():
             traffic = traffic_src = None
             try:
                 import glob
-                newest = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_traffic.json")))[-1]
+                suffix = {"2": "", "3": "_cfg3"}[args.config]   # (KeyError -> no committed PMC passes for this config)
+                newest = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic{suffix}.json")))[-1]
                 pmc = json.load(open(newest))["kernels"]
                 for kname, v in pmc.items():
-                    if dom in kname and (H, W, B, M, K) == (256, 256, 32, 192, 1):
+                    if dom in kname:
                         traffic = v["traffic_bytes_per_launch"]
                         traffic_src = os.path.relpath(newest, ROOT)
             except Exception:

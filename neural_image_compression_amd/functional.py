@@ -27,7 +27,7 @@ PROFILE_MIN_FLOP = 0.0   # launches below this many algorithmic FLOP are not bra
 # force_tm / force_tn / force_split; None = automatic).  The automatic tile depends on the batch, so the
 # parity tests use these to run every variant the full-size workloads dispatch against the oracle at small
 # sizes; codec.py pins one variant so encoder and decoder build identical tables.
-FORCE_IGEMM = None       # (bm, tn, split) -- 0 entries stay automatic
+FORCE_IGEMM = None       # (bm, tn, split[, bf16 DMA ring]) -- 0 entries stay automatic
 FORCE_WGRAD = None       # (tm, tn, split)
 KERNEL_TRACE = None      # set -> the rocprofv3 name of every MFMA kernel variant launched is added
 # id(parameter) -> (weakref, persistent gradient slot inside a data-parallel all-reduce bucket)
@@ -139,7 +139,7 @@ def _igemm(inp, w_packed, out, *, B, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, 
     ws = None
     fused = epilogue in (L.EPI_CONV_GDN, L.EPI_CONV_IGDN)
     if FORCE_IGEMM is not None:
-        d.force_bm, d.force_tn, d.force_split = FORCE_IGEMM
+        d.force_bm, d.force_tn, d.force_split = FORCE_IGEMM[:3]
     if KERNEL_TRACE is not None:
         KERNEL_TRACE.add(_kernel_name(lib.lic_igemm_kernel_name, d))
     if Ho * Wo <= 1024 and out2 is None and res is None:  # latent-side layers: allow split-K

@@ -76,7 +76,7 @@ def _igemm_bf16(inp, w_packed, out, *, B, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, str
             (Ho * Wo <= 192 or d.force_split > 1):
         # layers far too small to fill the chip split K across workgroups (fp32 partial tiles + a finishing launch);
         # the plan depends on the geometry only, so its workspace size is asked once per shape
-        key = (B, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, pad, bool(transposed), tap_mask, d.force_split)
+        key = (B, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, pad, bool(transposed), tap_mask, d.force_split, d.force_bm)
         nbytes = _SPLIT_WS.get(key)
         if nbytes is None:
             nbytes = _SPLIT_WS[key] = L.load().lic_igemm_bf16_workspace_bytes(C.byref(d))
@@ -96,8 +96,8 @@ def _igemm_bf16(inp, w_packed, out, *, B, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, str
         macs = B * Ho * Wo * (kh * kw) * Cin * Cout // 4
     else:
         macs = B * Ho * Wo * kh * kw * Cin * Cout
-    F_.PROFILE.append(("igemm_bf16_kernel", 2 * macs, 2 * B * Hi * Wi * Cin + out.element_size() * B * Ho * Wo * Cout,
-                       e0, e1))
+    F_.PROFILE.append((F_._kernel_name(L.load().lic_igemm_bf16_kernel_name, d), 2 * macs,
+                       2 * B * Hi * Wi * Cin + out.element_size() * B * Ho * Wo * Cout, e0, e1))
 
 
 def _wgrad_bf16(p, g, dst, *, B, Hs, Ws, Cp, Hl, Wl, Cg, kh, kw, stride, pad, g_is_row, dst_sm, dst_sn, dst_stap,
@@ -450,8 +450,12 @@ class _ConvGDNBF16Fn(torch.autograd.Function):
             from . import functional as F_
             if F_.KERNEL_TRACE is not None:
                 F_.KERNEL_TRACE.add(f"stem_gdn_bf16_kernel<{Cout // 32}, {8 if Cout == 192 else 4}>")
-            L.check(lib.lic_stem_gdn_bf16(_ptr(src), _ptr(wp), _ptr(bias), _ptr(gT), _ptr(beta_e), _ptr(y), _ptr(conv_out),
-                                          _ptr(norm), B, Hi, Wi, Cout, int(inverse), _stream()), "lic_stem_gdn_bf16")
+            Pn = B * Ho * Wo
+            F_._timed(f"stem_gdn_bf16_kernel<{Cout // 32}, {8 if Cout == 192 else 4}>",
+                      2 * Pn * Cout * (kh * kw * Cin + Cout), 4 * src.numel() + 2 * Pn * Cout * (3 if keep else 1),
+                      lambda: L.check(lib.lic_stem_gdn_bf16(_ptr(src), _ptr(wp), _ptr(bias), _ptr(gT), _ptr(beta_e), _ptr(y),
+                                                            _ptr(conv_out), _ptr(norm), B, Hi, Wi, Cout, int(inverse),
+                                                            _stream()), "lic_stem_gdn_bf16"))
         else:
             if stem:
                 src, wp, (B, Ho, Wo, Cout, Cin, Kp, P) = _stem_columns_bf16(x, weight, stride, pad)
