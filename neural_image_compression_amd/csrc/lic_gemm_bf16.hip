@@ -766,8 +766,8 @@ LIC_EXPORT int lic_igemm_bf16_kernel_name(const lic_igemm_desc* d, char* buf, si
   if (rc < 0) return rc;
   if (!buf || n == 0) return LIC_ERR_INVALID;
   const bool fuse = p.epilogue == LIC_EPI_CONV_GDN || p.epilogue == LIC_EPI_CONV_IGDN;
-  snprintf(buf, n, fuse ? "igemm_bf16_kernel<%d, %d, %s, true>" : "igemm_bf16_kernel<%d, %d, %s>", BM, TN,
-           p.prologue == 1 ? "true" : "false");
+  snprintf(buf, n, fuse ? "igemm_bf16_kernel<%d, %d, %s, true>" : "igemm_bf16_kernel<%d, %d, %s, false>", BM, TN,
+           p.prologue == 1 ? "true" : "false");  // (all four template arguments, as rocprofv3 prints them)
   return LIC_OK;
 }
 

@@ -17,6 +17,7 @@ from .functional import (PEDESTAL, _colsum, _nchw_view, _nhwc, _permute3, _ptr, 
                          prepared)
 
 BF16 = torch.bfloat16
+_NAMES = {}      # geometry -> kernel variant name (bench.py's event brackets)
 _SPLIT_WS = {}   # geometry -> K-split workspace bytes of lic_igemm_bf16 (0 = no split)
 
 
@@ -96,7 +97,11 @@ def _igemm_bf16(inp, w_packed, out, *, B, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, str
         macs = B * Ho * Wo * (kh * kw) * Cin * Cout // 4
     else:
         macs = B * Ho * Wo * kh * kw * Cin * Cout
-    F_.PROFILE.append((F_._kernel_name(L.load().lic_igemm_bf16_kernel_name, d), 2 * macs,
+    nkey = (B, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, pad, bool(transposed), prologue, epilogue, tap_mask, d.force_bm)
+    name = _NAMES.get(nkey)   # (planning the launch a second time for its name costs as much as the launch)
+    if name is None:
+        name = _NAMES[nkey] = F_._kernel_name(L.load().lic_igemm_bf16_kernel_name, d)
+    F_.PROFILE.append((name, 2 * macs,
                        2 * B * Hi * Wi * Cin + out.element_size() * B * Ho * Wo * Cout, e0, e1))
 
 
@@ -122,7 +127,11 @@ def _wgrad_bf16(p, g, dst, *, B, Hs, Ws, Cp, Hl, Wl, Cg, kh, kw, stride, pad, g_
     e0.record()
     L.check(lib.lic_wgrad_bf16(C.byref(d), _ptr(ws), nbytes, _stream()), "lic_wgrad_bf16")
     e1.record()
-    F_.PROFILE.append(("wgrad_bf16_kernel+reduce", 2 * B * Hs * Ws * kh * kw * Cp * Cg,
+    nkey = ("w", B, Hs, Ws, Cp, Hl, Wl, Cg, kh, kw, stride, pad, bool(g_is_row), sq_g)
+    name = _NAMES.get(nkey)
+    if name is None:
+        name = _NAMES[nkey] = F_._kernel_name(lib.lic_wgrad_bf16_kernel_name, d) + "+reduce"
+    F_.PROFILE.append((name, 2 * B * Hs * Ws * kh * kw * Cp * Cg,
                        2 * (B * Hs * Ws * Cp + B * Hl * Wl * Cg), e0, e1))
 
 
