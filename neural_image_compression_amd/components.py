@@ -15,9 +15,9 @@ class _Stack(nn.Module):
 
     def forward(self, x, out=None):
         if self.precision == "bf16":
-            if out is not None:
-                raise NotImplementedError
-            return run_bf16(self.net, x, self.out_f32)
+            if out is not None and (self.out_f32 or not isinstance(self.net[-1], Conv2d)):
+                raise NotImplementedError("`out` needs a stack that ends in a plain Conv2d and hands bf16 features on")
+            return run_bf16(self.net, x, self.out_f32, out)
         return run_fused(self.net, x, out)
 
 

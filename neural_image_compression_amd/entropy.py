@@ -160,7 +160,7 @@ class MaskedConv2d(Conv2d):
             F_.mask_weight_(self.weight, self.mask)
         s, p = self.stride[0], self.padding[0]
         if bf16:  # bf16 features out (they feed the bf16 entropy-parameter MLP)
-            return FB_.conv2d_bf16(x, self.weight, self.bias, s, p, False, False, 0.01, self._tap_mask)
+            return FB_.conv2d_bf16(x, self.weight, self.bias, s, p, False, False, 0.01, self._tap_mask, out)
         return F_.conv2d(x, self.weight, self.bias, s, p, False, 0.01, self._tap_mask, None, out)
 
 

@@ -357,7 +357,8 @@ class _JoinChannelsFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b, buf):
         ca, cb = a.shape[1], b.shape[1]
-        if buf.shape[-1] != ca + cb or a.data_ptr() != buf.data_ptr() or b.data_ptr() != buf.data_ptr() + 4 * ca:
+        if buf.shape[-1] != ca + cb or a.data_ptr() != buf.data_ptr() or \
+                b.data_ptr() != buf.data_ptr() + buf.element_size() * ca:
             raise ValueError("join_channels: the operands are not the two channel ranges of the buffer")
         ctx.ca = ca
         return _nchw_view(buf)

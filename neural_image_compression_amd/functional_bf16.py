@@ -59,11 +59,11 @@ def _pack_conv_weight_bf16(w, transposed_weight, for_dgrad):
 
 def _igemm_bf16(inp, w_packed, out, *, B, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, stride, pad, transposed, bias=None,
                 prologue=0, epilogue=L.EPI_NONE, out2=None, aux=None, aux2=None, aux3=None, slope=0.01, tap_mask=0,
-                out3=None):
+                out3=None, out_ld=None):
     d = L.IgemmDesc()
     d.in_, d.w, d.bias, d.out, d.out2 = _ptr(inp), _ptr(w_packed), _ptr(bias), _ptr(out), _ptr(out2)
     d.aux, d.aux2, d.aux3, d.res, d.out3 = _ptr(aux), _ptr(aux2), _ptr(aux3), None, _ptr(out3)
-    d.in_ld, d.out_ld = Cin, Cout
+    d.in_ld, d.out_ld = Cin, (Cout if out_ld is None else out_ld)
     d.out2_ld = d.aux_ld = d.aux2_ld = d.aux3_ld = d.res_ld = d.out3_ld = Cout
     d.B, d.Hi, d.Wi, d.Cin, d.Ho, d.Wo, d.Cout = B, Hi, Wi, Cin, Ho, Wo, Cout
     d.kh, d.kw, d.stride, d.pad = kh, kw, stride, pad
@@ -157,7 +157,8 @@ class _ConvBF16Fn(torch.autograd.Function):
     ParametersModels.py:22-34) and a tap mask (ContextModels.py:19-20)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, stride, pad, out_pad, transposed, out_f32, leaky=False, slope=0.01, tap_mask=0):
+    def forward(ctx, x, weight, bias, stride, pad, out_pad, transposed, out_f32, leaky=False, slope=0.01, tap_mask=0,
+                out_view=None):
         _check(x, weight, bias)
         xh = _as_bf16_nhwc(x)
         B, Hi, Wi, Cin = xh.shape
@@ -165,12 +166,22 @@ class _ConvBF16Fn(torch.autograd.Function):
         Cout = weight.shape[1] if transposed else weight.shape[0]
         Ho, Wo = conv_out_size(Hi, Wi, kh, stride, pad, transposed, out_pad)
         wp = _pack_conv_weight_bf16(weight, transposed, False)
-        out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32 if out_f32 else BF16)
+        out_ld = None
+        if out_view is not None:
+            # the caller's channel range of a wider bf16 NHWC buffer (two producers fill one tensor: no torch.cat)
+            if leaky or out_f32 or out_view.dtype != BF16 or tuple(out_view.shape) != (B, Ho, Wo, Cout) or \
+                    out_view.stride(3) != 1 or out_view.stride(2) % 8 or out_view.data_ptr() % 16 or \
+                    out_view.stride(1) != Wo * out_view.stride(2) or out_view.stride(0) != Ho * out_view.stride(1):
+                raise ValueError("out_view must be a 16-byte aligned [B,Ho,Wo,Cout] channel slice of a contiguous bf16 "
+                                 "NHWC buffer")
+            out, out_ld = out_view, out_view.stride(2)
+        else:
+            out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32 if out_f32 else BF16)
         if leaky and out_f32:
             raise NotImplementedError("the fused LeakyReLU keeps its mask in the bf16 output")
         _igemm_bf16(xh, wp, out, B=B, Hi=Hi, Wi=Wi, Cin=Cin, Ho=Ho, Wo=Wo, Cout=Cout, kh=kh, kw=kw, stride=stride,
                     pad=pad, transposed=transposed, bias=bias, epilogue=L.EPI_LEAKY if leaky else L.EPI_NONE,
-                    slope=slope, tap_mask=tap_mask)
+                    slope=slope, tap_mask=tap_mask, out_ld=out_ld)
         ctx.save_for_backward(xh, weight, out if leaky else None)
         ctx.cfg = (stride, pad, transposed, bias is not None, x.dtype, leaky, slope, tap_mask)
         return _nchw_view(out)
@@ -185,7 +196,7 @@ class _ConvBF16Fn(torch.autograd.Function):
         need = ctx.needs_input_grad
         dx, dw, db = _conv_backward_bf16(xh, weight, g, stride, pad, transposed, in_dtype, tap_mask, need[0], need[1],
                                          has_bias and need[2])
-        return dx, dw, db, None, None, None, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None, None, None, None
 
 
 def _conv_backward_bf16(xh, weight, g, stride, pad, transposed, in_dtype, tap_mask, need_dx, need_dw, need_db):
@@ -524,8 +535,9 @@ def conv_gdn_bf16(x, weight, bias, beta, gamma, stride, padding, inverse, beta_b
                                 _will_backprop(x, weight, bias, beta, gamma))
 
 
-def conv2d_bf16(x, weight, bias, stride, padding, out_f32=False, leaky=False, slope=0.01, tap_mask=0):
-    return _ConvBF16Fn.apply(x, weight, bias, stride, padding, 0, False, out_f32, leaky, slope, tap_mask)
+def conv2d_bf16(x, weight, bias, stride, padding, out_f32=False, leaky=False, slope=0.01, tap_mask=0, out=None):
+    """`out`: optional [B,Ho,Wo,Cout] channel slice of a wider contiguous bf16 NHWC buffer to write into"""
+    return _ConvBF16Fn.apply(x, weight, bias, stride, padding, 0, False, out_f32, leaky, slope, tap_mask, out)
 
 
 def conv_transpose2d_bf16(x, weight, bias, stride, padding, output_padding, out_f32=False, leaky=False, slope=0.01):

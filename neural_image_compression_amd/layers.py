@@ -29,8 +29,8 @@ class Conv2d(nn.Conv2d):
         if self.groups != 1 or _pair(self.dilation) != 1:
             raise NotImplementedError("groups/dilation are not used by the reference models")
         s, p = _pair(self.stride), _pair(self.padding)
-        if out is not None and (bf16 or self.in_channels < 4):
-            raise NotImplementedError("`out` slices are for the fp32 implicit-GEMM path")
+        if out is not None and self.in_channels < 4:
+            raise NotImplementedError("`out` slices are for the implicit-GEMM path")
         if bf16:  # bf16-storage path (BASELINE config 3): conv + bias (+ fused LeakyReLU)
             if residual is not None:
                 raise NotImplementedError("bf16 mode covers the 5x5 conv/GDN stacks and the latent-side layers")
@@ -38,7 +38,7 @@ class Conv2d(nn.Conv2d):
                 if leaky:
                     raise NotImplementedError
                 return FB_.image_conv2d_bf16(x, self.weight, self.bias, s, p)
-            return FB_.conv2d_bf16(x, self.weight, self.bias, s, p, out_f32, leaky, slope)
+            return FB_.conv2d_bf16(x, self.weight, self.bias, s, p, out_f32, leaky, slope, 0, out)
         if self.in_channels < 4:  # RGB stem: im2col + dense MFMA GEMM
             y = F_.image_conv2d(x, self.weight, self.bias, s, p, leaky, slope)
             return y if residual is None else y + residual
@@ -78,7 +78,7 @@ class LeakyReLU(nn.Module):
         return F_.leaky_relu(x, self.negative_slope)
 
 
-def run_bf16(seq: nn.Sequential, x: Tensor, out_f32: bool = True) -> Tensor:
+def run_bf16(seq: nn.Sequential, x: Tensor, out_f32: bool = True, out=None) -> Tensor:
     """bf16-storage execution of a stack: bf16 between layers (Conv -> LeakyReLU pairs as one launch), the
     last layer writes fp32 when `out_f32` (latents, entropy parameters, the image) and bf16 otherwise
     (features that only feed another bf16 layer)."""
@@ -102,7 +102,10 @@ def run_bf16(seq: nn.Sequential, x: Tensor, out_f32: bool = True) -> Tensor:
                                      output_padding=_pair(m.output_padding) if tr else 0)
                 i += 2
                 continue
-            x = m(x, bf16=True, out_f32=(out_f32 and i == len(mods) - 1))
+            if out is not None and i == len(mods) - 1:   # the stack's result goes into the caller's channel slice
+                x = m(x, bf16=True, out=out)
+            else:
+                x = m(x, bf16=True, out_f32=(out_f32 and i == len(mods) - 1))
         elif isinstance(m, GDN):
             x = m(x, bf16=True)
         else:

@@ -89,13 +89,16 @@ class _HyperpriorContextModel(nn.Module):
             _fork(y_in)
         z = self.hyper_encoder(y)
         z_in = F_.quantize(z, uz, True) if training else F_.quantize(z, None, False)
-        if x.is_cuda and self.context_model.precision == "fp32" and self.hyper_decoder.precision == "fp32":
+        both = (self.context_model.precision, self.hyper_decoder.precision)
+        if x.is_cuda and (both == ("fp32", "fp32") or (both == ("bf16", "bf16") and not self.hyper_decoder.out_f32)):
             # Models.py:73 `torch.cat([phi, psi], dim=1)` without the copy: the context conv and the hyper
-            # decoder's last conv write the two channel ranges of one NHWC buffer (phi first)
+            # decoder's last conv write the two channel ranges of one NHWC buffer (phi first; fp32, or bf16 when
+            # both producers hand bf16 features to the bf16 entropy-parameter MLP)
             Bn, _, hh, ww = y_in.shape
             c_phi = self.context_model.masked.out_channels
             c_psi = self.hyper_decoder.net[-1].out_channels
-            comb = torch.empty((Bn, hh, ww, c_phi + c_psi), device=x.device, dtype=torch.float32)
+            comb = torch.empty((Bn, hh, ww, c_phi + c_psi), device=x.device,
+                               dtype=torch.float32 if both[0] == "fp32" else torch.bfloat16)
             psi = self.hyper_decoder(z_in, out=comb[..., c_phi:])
             phi = self.context_model(y_in, out=comb[..., :c_phi])
             combined = F_.join_channels(phi, psi, comb)
