@@ -228,25 +228,34 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
       __builtin_amdgcn_global_load_lds((lich_gptr_t)(wsrc + j * 2048), (lich_lptr_t)(dstB + j * 2048 + wave * 512),
                                        16, 0, 0);
   };
-  auto compute = [&](auto bufc) {
+  // A step reads ALL its fragments first (TM*2 + TW*2 ds_read_b128), then issues the next chunk's DMAs -- ~40
+  // scalar / vector address instructions -- and only then runs the MFMAs: the LDS latency hides under the address
+  // arithmetic instead of standing in front of the first MFMA (left to itself hipcc placed each pair of reads
+  // directly before its use, three exposed LDS round trips per chunk).
+  bf16x8 af[TM][2], bf[TW][2];
+  auto load_frags = [&](auto bufc) {
     constexpr int buf = decltype(bufc)::value;
     const bf16_t* bA = bufp(buf);
     const bf16_t* bB = bA + BM * HB_BK + (wn0 >> 5) * 1024 + lane * 8;
-    bf16x8 af[TM][2], bf[TW][2];
 #pragma unroll
     for (int a = 0; a < TM; ++a) {
       const int row = wm0 + a * 32 + li;
       const int sw = (row >> 2) & 3;
 #pragma unroll
-      for (int q = 0; q < 2; ++q) {
-        af[a][q] = *reinterpret_cast<const bf16x8*>(bA + row * HB_BK + (((q * 2 + lh) ^ sw) * 8));
-        if constexpr (SQ) af[a][q] = sq8(af[a][q]);
-      }
+      for (int q = 0; q < 2; ++q) af[a][q] = *reinterpret_cast<const bf16x8*>(bA + row * HB_BK + (((q * 2 + lh) ^ sw) * 8));
     }
 #pragma unroll
     for (int b = 0; b < TW; ++b)
 #pragma unroll
       for (int q = 0; q < 2; ++q) bf[b][q] = *reinterpret_cast<const bf16x8*>(bB + (b * 2 + q) * 512);
+  };
+  auto mfmas = [&]() {
+    if constexpr (SQ) {
+#pragma unroll
+      for (int a = 0; a < TM; ++a)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) af[a][q] = sq8(af[a][q]);
+    }
 #pragma unroll
     for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -285,9 +294,12 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
     advance();
     auto step = [&](auto cur, auto fill) {
       asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(NL) : "memory");
+      load_frags(cur);
+      __builtin_amdgcn_sched_barrier(0);
       issue(l_tap, l_cb, fill);
       advance();
-      compute(cur);
+      __builtin_amdgcn_sched_barrier(0);
+      mfmas();
       __builtin_amdgcn_sched_barrier(0);
     };
     int c = 0;
