@@ -52,7 +52,7 @@ enum lic_epilogue {
   LIC_EPI_GDN_BWD = 5,        /* v = aux * rsqrt(aux3) + 2 * aux2 * acc                       */
   LIC_EPI_IGDN_BWD = 6,       /* v = aux * sqrt(aux3)  + 2 * aux2 * acc                       */
   /* convolution + the GDN / IGDN that follows it, in one kernel (lic_igemm_fused_gdn_supported):
-   *   x = acc + bias -> out3 (may be NULL);  n = aux2 + x^2 . aux -> out2;  out = x * rsqrt(n) | x * sqrt(n)
+   *   x = acc + bias -> out3 (may be NULL);  n = aux2 + x^2 . aux -> out2 (may be NULL);  out = x * rsqrt(n) | x * sqrt(n)
    *   aux = gamma_eff^T packed by lic_pack_weight(taps=1, K=Cout, N=Cout), aux2 = beta_eff [Cout].
    *   Bitwise identical to LIC_EPI_NONE followed by a prologue=1 / LIC_EPI_GDN contraction launch. */
   LIC_EPI_CONV_GDN = 7,
@@ -320,7 +320,8 @@ int lic_gdn_dnorm_bf16(const void* g, const void* x, const void* norm, void* t, 
  * Stand-alone GDN / IGDN (compressai GDN at Components.py:11-44, Layers.py:41,75)
  * for C in {64,128,192} (lic_gdn_supported): one sweep over the activation per launch, the C x C pool
  * on MFMA out of an LDS tile.  x, y, norm, g, dx, t: dense [P][C] fp32 (NHWC activations, P = B*H*W).
- *   lic_gdn_fwd: norm = beta_eff + x^2 . gamma_eff^T; y = x * rsqrt(norm) (inverse: * sqrt(norm)) (+ res)
+ *   lic_gdn_fwd: norm = beta_eff + x^2 . gamma_eff^T (written unless `norm` is NULL: only the backward pass reads
+ *                it); y = x * rsqrt(norm) (inverse: * sqrt(norm)) (+ res)
  *                gammaT_packed = lic_pack_weight(gamma_eff, taps=1, K=C, N=C, s_k=1, s_n=C)
  *   lic_gdn_bwd: t = dL/dnorm (written: the d-gamma / d-beta launches read it),
  *                dx = g * rsqrt(norm) + 2 x (t . gamma_eff)  (inverse: g * sqrt(norm) + ...)

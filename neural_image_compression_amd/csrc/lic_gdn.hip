@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void gdn_kernel(const GdnParams p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e)
           o[e] = x4[e] * (inv ? __builtin_amdgcn_sqrtf(n4[e]) : __builtin_amdgcn_rsqf(n4[e]));
-        *reinterpret_cast<f32x4*>(p.out2 + off) = n4;
+        if (p.out2) *reinterpret_cast<f32x4*>(p.out2 + off) = n4;
         if (p.res) o += *reinterpret_cast<const f32x4*>(p.res + off);
       } else {
         const f32x4 n4 = *reinterpret_cast<const f32x4*>(p.norm + off);
@@ -366,7 +366,7 @@ LIC_EXPORT int lic_gdn_supported(int32_t C) { return C == 64 || C == 128 || C ==
 
 LIC_EXPORT int lic_gdn_fwd(const float* x, const float* gammaT_packed, const float* beta_eff, const float* res,
                            float* y, float* norm, int64_t P, int32_t C, int32_t inverse, lic_stream_t stream) {
-  if (!x || !gammaT_packed || !beta_eff || !y || !norm || P <= 0) return LIC_ERR_INVALID;
+  if (!x || !gammaT_packed || !beta_eff || !y || P <= 0) return LIC_ERR_INVALID;  // (norm may be NULL: inference)
   if (!lic_gdn_supported(C)) return LIC_ERR_UNSUPPORTED;
   if (!gd_al16(x) || !gd_al16(gammaT_packed) || !gd_al16(beta_eff) || !gd_al16(y) || !gd_al16(norm) || !gd_al16(res))
     return LIC_ERR_INVALID;

@@ -635,7 +635,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmParams p) {
           for (int e = 0; e < 4; ++e)
             y4[e] = x4[e] * (inv ? __builtin_amdgcn_sqrtf(n4[e]) : __builtin_amdgcn_rsqf(n4[e]));
           if (p.out3) *reinterpret_cast<f32x4*>(p.out3 + opix[it] * p.out3_ld + col) = x4;
-          *reinterpret_cast<f32x4*>(p.out2 + opix[it] * p.out2_ld + col) = n4;
+          if (p.out2) *reinterpret_cast<f32x4*>(p.out2 + opix[it] * p.out2_ld + col) = n4;
           *reinterpret_cast<f32x4*>(p.out + opix[it] * p.out_ld + col) = y4;
         }
         __builtin_amdgcn_wave_barrier();
@@ -1015,7 +1015,7 @@ static int igemm_prepare(const lic_igemm_desc* d, IgemmParams& p, int& BM, int& 
   }
   const bool fuse = (epi == LIC_EPI_CONV_GDN || epi == LIC_EPI_CONV_IGDN);
   if (fuse) {
-    if (!d->aux || !d->aux2 || !d->out2 || d->res || d->prologue) return LIC_ERR_INVALID;
+    if (!d->aux || !d->aux2 || d->res || d->prologue) return LIC_ERR_INVALID;  // (out2 / out3 may be NULL: inference)
     if (!lic_igemm_fused_gdn_supported(d->Cin, d->Cout)) return LIC_ERR_UNSUPPORTED;
     if (!aligned16(d->aux)) return LIC_ERR_INVALID;
   }

@@ -503,7 +503,7 @@ class _ImageConvGDNFn(torch.autograd.Function):
     """The RGB stem and the GDN behind it (Components.py:10-11) with the pool fused into the GEMM."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, beta, gamma, stride, pad, inverse, beta_bound, gamma_bound, pedestal):
+    def forward(ctx, x, weight, bias, beta, gamma, stride, pad, inverse, beta_bound, gamma_bound, pedestal, keep=True):
         _require_cuda(x, weight, bias, beta, gamma)
         xh = _nhwc(x)
         B = xh.shape[0]
@@ -511,9 +511,9 @@ class _ImageConvGDNFn(torch.autograd.Function):
         col, wp, Ho, Wo, Kp = _image_conv_columns(xh, weight, stride, pad)
         P = B * Ho * Wo
         beta_e, gT = _gdn_operands(beta, gamma, beta_bound, gamma_bound, pedestal)
-        conv_out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
-        norm = torch.empty_like(conv_out)
-        y = torch.empty_like(conv_out)
+        y = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+        conv_out = torch.empty_like(y) if keep else None   # (only the backward pass reads these two)
+        norm = torch.empty_like(y) if keep else None
         _igemm(col, wp, y, B=1, Hi=1, Wi=P, Cin=Kp, Ho=1, Wo=P, Cout=Cout, kh=1, kw=1, stride=1,
                pad=0, transposed=False, bias=bias, epilogue=L.EPI_CONV_IGDN if inverse else L.EPI_CONV_GDN,
                out2=norm, out3=conv_out, aux=gT, aux2=beta_e)
@@ -530,7 +530,7 @@ class _ImageConvGDNFn(torch.autograd.Function):
                                               beta_bound, gamma_bound, pedestal, True, need[3], need[4])
         dx, dw, db = _image_conv_backward(col, weight, g_conv, stride, pad, in_shape, need[0], need[1],
                                           has_bias and need[2])
-        return dx, dw, db, dbeta, dgamma, None, None, None, None, None, None
+        return dx, dw, db, dbeta, dgamma, None, None, None, None, None, None, None
 
 
 class _ImageConvTFn(torch.autograd.Function):
@@ -636,14 +636,14 @@ def leaky_relu(x, slope=0.01):
 # ------------------------------------------------------------------------------------------
 class _GDNFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, beta, gamma, inverse, beta_bound, gamma_bound, pedestal, res):
+    def forward(ctx, x, beta, gamma, inverse, beta_bound, gamma_bound, pedestal, res, keep=True):
         _require_cuda(x, beta, gamma, res)
         lib = L.load()
         xh = _nhwc(x)
         B, H, W, Cc = xh.shape
         beta_e, gT = _gdn_operands(beta, gamma, beta_bound, gamma_bound, pedestal)
         out = torch.empty_like(xh)
-        norm = torch.empty_like(xh)
+        norm = torch.empty_like(xh) if keep else None   # (only the backward pass reads it)
         resh = None if res is None else _nhwc(res)
         P = B * H * W
         if lib.lic_gdn_supported(Cc):
@@ -670,7 +670,7 @@ class _GDNFn(torch.autograd.Function):
         dx = None if dxh is None else _nchw_view(dxh)
         if dx is not None and hasattr(dxh, "_lic_colsum_partial"):
             dx._lic_colsum_partial = dxh._lic_colsum_partial  # rides along to the producing conv's backward
-        return dx, dbeta, dgamma, None, None, None, None, dres
+        return dx, dbeta, dgamma, None, None, None, None, dres, None
 
 
 def _gdn_operands(beta, gamma, beta_bound, gamma_bound, pedestal):
@@ -778,7 +778,7 @@ class _ConvGDNFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, weight, bias, beta, gamma, stride, pad, out_pad, transposed, inverse, beta_bound,
-                gamma_bound, pedestal):
+                gamma_bound, pedestal, keep=True):
         _require_cuda(x, weight, bias, beta, gamma)
         xh = _nhwc(x)
         B, Hi, Wi, Cin = xh.shape
@@ -787,9 +787,9 @@ class _ConvGDNFn(torch.autograd.Function):
         Ho, Wo = conv_out_size(Hi, Wi, kh, stride, pad, transposed, out_pad)
         wp = _pack_conv_weight(weight, transposed, for_dgrad=False)
         beta_e, gT = _gdn_operands(beta, gamma, beta_bound, gamma_bound, pedestal)
-        conv_out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
-        norm = torch.empty_like(conv_out)
-        y = torch.empty_like(conv_out)
+        y = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+        conv_out = torch.empty_like(y) if keep else None   # (only the backward pass reads these two)
+        norm = torch.empty_like(y) if keep else None
         _igemm(xh, wp, y, B=B, Hi=Hi, Wi=Wi, Cin=Cin, Ho=Ho, Wo=Wo, Cout=Cout, kh=kh, kw=kw, stride=stride,
                pad=pad, transposed=transposed, bias=bias,
                epilogue=L.EPI_CONV_IGDN if inverse else L.EPI_CONV_GDN, out2=norm, out3=conv_out, aux=gT,
@@ -807,7 +807,14 @@ class _ConvGDNFn(torch.autograd.Function):
                                               beta_bound, gamma_bound, pedestal, True, need[3], need[4])
         dx, dw, db = _conv_backward(xh, weight, g_conv, stride, pad, transposed, 0, need[0], need[1],
                                     has_bias and need[2])
-        return dx, dw, db, dbeta, dgamma, None, None, None, None, None, None, None, None
+        return dx, dw, db, dbeta, dgamma, None, None, None, None, None, None, None, None, None
+
+
+def will_backprop(*ts) -> bool:
+    """True when autograd will record the op being built.  Inside Function.forward grad mode is always off and
+    ctx.needs_input_grad ignores torch.no_grad(), so the wrappers ask before .apply: tensors that only the backward
+    pass reads (the GDN norm, the convolution output in front of a fused GDN) are written only then."""
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
 
 
 def fused_gdn_supported(cin: int, cout: int) -> bool:
@@ -838,14 +845,16 @@ def conv_gdn(x, weight, bias, beta, gamma, stride, padding, inverse, beta_bound,
     """`gdn(conv2d(x))` / `gdn(conv_transpose2d(x))` in one launch (see _ConvGDNFn)."""
     if not transposed and weight.shape[1] < 4:  # RGB stem: columns + dense GEMM
         return _ImageConvGDNFn.apply(x, weight, bias, beta, gamma, stride, padding, bool(inverse),
-                                     float(beta_bound), float(gamma_bound), float(pedestal))
+                                     float(beta_bound), float(gamma_bound), float(pedestal),
+                                     will_backprop(x, weight, bias, beta, gamma))
     return _ConvGDNFn.apply(x, weight, bias, beta, gamma, stride, padding, output_padding, bool(transposed),
-                            bool(inverse), float(beta_bound), float(gamma_bound), float(pedestal))
+                            bool(inverse), float(beta_bound), float(gamma_bound), float(pedestal),
+                            will_backprop(x, weight, bias, beta, gamma))
 
 
 def gdn(x, beta, gamma, inverse, beta_bound, gamma_bound, pedestal=PEDESTAL, residual=None):
     return _GDNFn.apply(x, beta, gamma, bool(inverse), float(beta_bound), float(gamma_bound),
-                        float(pedestal), residual)
+                        float(pedestal), residual, will_backprop(x, beta, gamma, residual))
 
 
 # ------------------------------------------------------------------------------------------

@@ -516,11 +516,7 @@ class _ConvGDNBF16Fn(torch.autograd.Function):
         return dx, dw, db, dbeta, dgamma, None, None, None, None, None, None, None, None, None
 
 
-def _will_backprop(*ts):
-    """True when autograd will record the op being built (inside Function.forward grad mode is always off and
-    needs_input_grad ignores torch.no_grad(), so the wrappers ask before .apply): tensors that only the backward
-    pass reads are written only then"""
-    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
+from .functional import will_backprop as _will_backprop  # noqa: E402
 
 
 def fused_gdn_supported_bf16(cin: int, cout: int) -> bool:

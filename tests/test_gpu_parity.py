@@ -231,6 +231,15 @@ def test_conv_gdn_fused(env, kind, ci, co, H, W, B, inverse):
         outs[fuse] = [y.detach(), tx.grad] + [p_.grad for p_ in seq.parameters()]
     for a, b in zip(outs[True], outs[False]):
         assert torch.equal(a, b), "fused conv+GDN differs from the two-launch path"
+    # inference: under no_grad the tensors only a backward pass reads (conv output, norm) are not written;
+    # y is the same launch's y
+    for fuse in (True, False):
+        LY.FUSE_CONV_GDN = fuse
+        try:
+            with torch.no_grad():
+                assert torch.equal(LY.run_fused(seq, dev_nchw(x, dev, False)), outs[True][0])
+        finally:
+            LY.FUSE_CONV_GDN = "auto"
     # oracle
     w, b = host(conv.weight), host(conv.bias)
     xc = O.convT2d_fwd(x, w, b, 2, 2, 1) if tr else O.conv2d_fwd(x, w, b, 2, 2)
