@@ -51,6 +51,7 @@ struct IgemmHParams {
   int cpt, Npad, nphase, MT, NT;
   int ksplit, cps;  // K split across workgroups (1 = none): chunks per split; fp32 partial tiles go to `slabs`
   float* slabs;     // [ksplit][B*Ho*Wo][Cout]
+  int ring;         // host side only: the RING template argument of the launch
   int pgroup, porder;  // 4-phase launches: phase-sorted groups of `pgroup` M tiles, order 2 bits per rank
   int ntaps[4];
   int Hq[4], Wq[4];
@@ -80,7 +81,15 @@ __device__ __forceinline__ bf16x8 sq8(bf16x8 v) {
 // v_permlane32_swap per dword pair turns a lane's 4+4 channels into 8 consecutive ones for 16-byte stores.
 // The element-wise part is written with 2-wide vectors (v_pk_add/mul_f32, v_cvt_pk_bf16_f32): at 2^26 outputs
 // per launch of the first layer every VALU instruction per element is 1.7 us.
-template <int BM, int TN, bool SQ = false, bool FUSE = false>
+template <int... Is, class F>
+__device__ __forceinline__ void lich_for_seq(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
+
+// RING: LDS buffers of the DMA ring (chunks RING-1 ahead).  Three for most variants; the 128 x 128 tile runs on
+// four (64 KB: still two workgroups per CU): with a chunk taking 0.3-0.6 us of a workgroup's time, two chunks
+// ahead is shorter than a loaded memory round trip.
+template <int BM, int TN, bool SQ = false, bool FUSE = false, int RING = 3>
 __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
   constexpr int BN = 64 * TN;
   constexpr int WGN = FUSE ? 1 : 2, WGM = 4 / WGN;  // wave grid
@@ -93,7 +102,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
   // three DMA buffers, later reused as the fp32 staging area of the epilogue (4 KiB per wave);
   // a plain 2-D array indexed with compile-time buffer numbers, so hipcc can tell the buffers apart
   constexpr int BUFP = (3 * BUF * 2 >= 4 * 4096) ? BUF : (4 * 4096 / 2 + 2) / 3;
-  __shared__ __attribute__((aligned(16))) bf16_t smem_all[3 * BUFP + 64];  // + the decoded tap list
+  __shared__ __attribute__((aligned(16))) bf16_t smem_all[RING * BUFP + 64];  // + the decoded tap list
   auto bufp = [&](int b) { return smem_all + b * BUFP; };
 
   const int tid = threadIdx.x;
@@ -175,7 +184,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
   // global load whose wait drains the whole in-order DMA queue
   // (kept INSIDE the one staging array: a second __shared__ object next to LDS-DMA buffers makes
   // hipcc wait vmcnt(0) before every LDS read)
-  int* s_taps = reinterpret_cast<int*>(smem_all + 3 * BUFP);
+  int* s_taps = reinterpret_cast<int*>(smem_all + RING * BUFP);
   if (tid < 28) {
     const int tt = p.taps[phase][tid < ntaps ? tid : 0];
     const int tr = tt / p.kw;
@@ -281,35 +290,32 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
     // nothing: the last analysis layer 33 -> 36 us, the 3x3 hyper layer 15 -> 17 us.  Their 0.33 us per chunk
     // is not memory latency but one wave per SIMD walking ds_read -> wait -> MFMA -> barrier with nothing else
     // to issue; more workgroups per CU (the K split below) is what helps.)
-    // Ring of three buffers, unrolled by three so that buffer indices are compile-time constants.
-    // At the top of a step the DMAs of chunks c and c+1 are in flight: vmcnt(NL) retires mine of
+    // Ring of RING buffers, unrolled by RING so that buffer indices are compile-time constants.
+    // At the top of a step the DMAs of chunks c .. c+RING-2 are in flight: vmcnt((RING-2)*NL) retires mine of
     // chunk c, the barrier says everyone's landed and everyone finished reading chunk c-1, whose
-    // buffer takes chunk c+2 (past-the-end chunks are clamped duplicates, so NL is exact).
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>;
-    issue(l_tap, l_cb, I0{});
-    advance();
-    issue(l_tap, l_cb, I1{});
-    advance();
-    auto step = [&](auto cur, auto fill) {
-      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(NL) : "memory");
+    // buffer takes chunk c+RING-1 (past-the-end chunks are clamped duplicates, so the count is exact).
+    static_assert(RING >= 3 && (RING - 2) * NL <= 63, "vmcnt is a 6-bit counter");
+    auto step = [&](auto cur) {
+      constexpr int CUR = decltype(cur)::value;
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"((RING - 2) * NL) : "memory");
       load_frags(cur);
       __builtin_amdgcn_sched_barrier(0);
-      issue(l_tap, l_cb, fill);
+      issue(l_tap, l_cb, std::integral_constant<int, (CUR + RING - 1) % RING>{});
       advance();
       __builtin_amdgcn_sched_barrier(0);
       mfmas();
       __builtin_amdgcn_sched_barrier(0);
     };
+    lich_for_seq(std::make_integer_sequence<int, RING - 1>{}, [&](auto i) {
+      issue(l_tap, l_cb, i);
+      advance();
+    });
     int c = 0;
-    for (; c + 2 < nchunks; c += 3) {
-      step(I0{}, I2{});
-      step(I1{}, I0{});
-      step(I2{}, I1{});
-    }
-    if (c < nchunks) step(I0{}, I2{});
-    if (c + 1 < nchunks) step(I1{}, I0{});
+    for (; c + RING - 1 < nchunks; c += RING) lich_for_seq(std::make_integer_sequence<int, RING>{}, step);
+    const int left = nchunks - c;
+    lich_for_seq(std::make_integer_sequence<int, RING>{}, [&](auto i) {
+      if (decltype(i)::value < left) step(i);
+    });
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // the epilogue reuses the buffers
   }
@@ -749,6 +755,10 @@ static int igemmh_prepare(const lic_igemm_desc* d, int32_t out_f32, IgemmHParams
     }
   }
   if (nwg > 0x7FFFFFFFL) return LIC_ERR_UNSUPPORTED;
+  {
+    const char* e = getenv("LIC_BF16_RING");  // tuning aid: 3 = the three-buffer ring everywhere
+    p.ring = (BM == 128 && TN <= 2 && p.prologue != 1 && !(e && e[0] == '3')) ? 4 : 3;
+  }
   return LIC_OK;
 }
 
@@ -778,8 +788,9 @@ LIC_EXPORT int lic_igemm_bf16_kernel_name(const lic_igemm_desc* d, char* buf, si
   if (rc < 0) return rc;
   if (!buf || n == 0) return LIC_ERR_INVALID;
   const bool fuse = p.epilogue == LIC_EPI_CONV_GDN || p.epilogue == LIC_EPI_CONV_IGDN;
-  snprintf(buf, n, fuse ? "igemm_bf16_kernel<%d, %d, %s, true>" : "igemm_bf16_kernel<%d, %d, %s, false>", BM, TN,
-           p.prologue == 1 ? "true" : "false");  // (all four template arguments, as rocprofv3 prints them)
+  // (all five template arguments, as rocprofv3 prints them)
+  snprintf(buf, n, "igemm_bf16_kernel<%d, %d, %s, %s, %d>", BM, TN, p.prologue == 1 ? "true" : "false",
+           fuse ? "true" : "false", p.ring);
   return LIC_OK;
 }
 
@@ -795,10 +806,15 @@ LIC_EXPORT int lic_igemm_bf16(const lic_igemm_desc* d, int32_t out_f32, lic_stre
   const bool fuse = p.epilogue == LIC_EPI_CONV_GDN || p.epilogue == LIC_EPI_CONV_IGDN;
 #define LIC_IGEMMH_LAUNCH(bm, tn)                                                           \
   do {                                                                                      \
-    if (fuse)                                                                               \
+    constexpr int R4 = (tn <= 2) ? 4 : 3; /* the ring p.ring asks for on 128-row tiles */   \
+    if (fuse && p.ring == 4)                                                                \
+      hipLaunchKernelGGL((igemm_bf16_kernel<128, tn, false, true, R4>), grid, block, 0, s, p); \
+    else if (fuse)                                                                          \
       hipLaunchKernelGGL((igemm_bf16_kernel<128, tn, false, true>), grid, block, 0, s, p);  \
     else if (p.prologue == 1)                                                               \
       hipLaunchKernelGGL((igemm_bf16_kernel<bm, tn, true>), grid, block, 0, s, p);          \
+    else if (p.ring == 4)                                                                   \
+      hipLaunchKernelGGL((igemm_bf16_kernel<128, tn, false, false, R4>), grid, block, 0, s, p); \
     else                                                                                    \
       hipLaunchKernelGGL((igemm_bf16_kernel<bm, tn>), grid, block, 0, s, p);                \
   } while (0)
