@@ -89,15 +89,31 @@ __device__ __forceinline__ void lich_for_seq(std::integer_sequence<int, Is...>, 
 // RING: LDS buffers of the DMA ring (chunks RING-1 ahead).  Three for most variants; the 128 x 128 tile runs on
 // four (64 KB: still two workgroups per CU): with a chunk taking 0.3-0.6 us of a workgroup's time, two chunks
 // ahead is shorter than a loaded memory round trip.
-template <int BM, int TN, bool SQ = false, bool FUSE = false, int RING = 3>
-__global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
+//
+// NWV = 8 (BM = 256, RING = 4, one workgroup per CU): the PING-PONG variant of the big layers.  Waves 0-3 own the
+// upper 128 rows of the tile, waves 4-7 the lower 128 (each SIMD hosts one wave of either group), both share the
+// weight panel, and the groups run HALF A CHUNK APART: a chunk is a load phase (wait for the DMA, read all
+// fragments, issue the DMAs three chunks ahead, wait for the fragments) and an MFMA phase, a workgroup barrier
+// after each -- while one group's waves occupy the matrix pipe the other group's do their LDS / address / DMA
+// work on the same SIMDs, instead of two independent workgroups colliding at random (PMC of the 4-wave kernel on
+// the 107-GFLOP layer: 37 % of wave cycles parked, 35 % issue-stalled).  Group g DMAs only its own 128 rows of A
+// (no cross-group dependency there) and half the weight panel; a wave of group 1 therefore waits one chunk
+// further than it needs itself (vmcnt(NL) instead of vmcnt(2 NL)), so that its share of chunk c's panel has
+// landed before the barrier in front of group 0's read of it.  A buffer is refilled only after both groups waited
+// lgkmcnt(0) on their reads of it and passed a barrier.  Same chunk and k order per output as the 4-wave
+// kernel: the results are bitwise the same.
+template <int BM, int TN, bool SQ = false, bool FUSE = false, int RING = 3, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV) void igemm_bf16_kernel(const IgemmHParams p) {
   constexpr int BN = 64 * TN;
-  constexpr int WGN = FUSE ? 1 : 2, WGM = 4 / WGN;  // wave grid
+  constexpr int NTH = 64 * NWV;                       // threads
+  constexpr int WGN = FUSE ? 1 : 2, WGM = NWV / WGN;  // wave grid
   constexpr int WM = BM / WGM, WN = BN / WGN;
-  constexpr int TM = WM / 32, TW = WN / 32;         // 32x32 MFMA tiles per wave
-  static_assert(!FUSE || (BM == 128 && !SQ), "the fused pool runs on 128-row tiles");
-  constexpr int APASS = BM / 64;              // 16-byte DMA pieces per thread per A tile
-  constexpr int NL = APASS + TN;              // DMA instructions per thread per chunk
+  constexpr int TM = WM / 32, TW = WN / 32;           // 32x32 MFMA tiles per wave
+  static_assert(!FUSE || (BM == 32 * NWV && !SQ), "the fused pool gives every wave 32 rows of all channels");
+  static_assert(NWV == 4 || (NWV == 8 && BM == 256 && RING == 4 && !SQ), "ping-pong variant: 256 rows, 8 waves");
+  constexpr int APASS = BM / (NTH / 4);       // 16-byte DMA pieces per thread per A tile
+  constexpr int BPASS = (256 * TN + NTH - 1) / NTH;  // ... per weight panel (NWV = 8: wrapped duplicates fill the last pass)
+  constexpr int NL = APASS + BPASS;           // DMA instructions per thread per chunk
   constexpr int BUF = (BM + BN) * HB_BK;      // bf16 elements of one (A tile, B panel) buffer
   // three DMA buffers, later reused as the fp32 staging area of the epilogue (4 KiB per wave);
   // a plain 2-D array indexed with compile-time buffer numbers, so hipcc can tell the buffers apart
@@ -150,11 +166,14 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
   // ds_read_b128 lane group would share banks, so slot s of row r holds K-octet s ^ ((r>>2)&3):
   // applied to the per-lane SOURCE address here and to the fragment reads below.
   const int gq = ((tid & 3) ^ ((tid >> 4) & 3)) * 8;  // this thread's logical channel offset in a chunk
+  // NWV = 8: group g = wave / 4 loads (and reads) only rows 128 g .. 128 g + 127
+  const int grp = (NWV == 8) ? (wave >> 2) : 0;
+  const int arow0 = (NWV == 8) ? 128 * grp + ((tid & 255) >> 2) : (tid >> 2);
   int a_base[APASS], a_hy[APASS], a_wx[APASS];
   bool a_ok[APASS];
 #pragma unroll
   for (int j = 0; j < APASS; ++j) {
-    const int prow = m0 + (tid >> 2) + 64 * j;
+    const int prow = m0 + arow0 + 64 * j;
     a_ok[j] = prow < P;
     const int pr = a_ok[j] ? prow : 0;
     const int b = fdivb(pr, p.dHW[phase]);
@@ -196,46 +215,68 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
   const int nchunks = (p.ksplit > 1 ? (c_lo + p.cps < nch_all ? p.cps : nch_all - c_lo) : nch_all);
   const int sgn = p.transposed ? -1 : 1;
   const int sh = (p.transposed && p.stride == 2) ? 1 : 0;
-  const int last_tap = ntaps - 1, last_cb = p.cpt - 1;
+  const int last_tap = ntaps - 1;
   const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_lic_zero16h);
-  // Per-tap gather state: the pixel a row reads changes only when the tap does (every cpt chunks);
-  // inside a tap a chunk just moves 32 channels on.  With 12-18 MFMAs of 32 cycles per chunk the
-  // full address computation (~70 VALU) per chunk would cost as much as the matrix work itself.
-  long t_off[APASS];
-  bool t_ok[APASS];
+  // Per-tap gather state: the pixel a row reads changes only when the tap does (every cpt chunks); inside a tap a
+  // chunk just moves 32 channels on.  The DMA sources are therefore RUNNING POINTERS: a tap change (once per cpt
+  // chunks) computes them in full (~70 VALU), every other chunk is one 64-bit add per piece -- the 46 SALU + 45
+  // VALU instructions a chunk used to spend on addresses were as long as its 8 MFMAs, and in the 8-wave variant
+  // they ARE the load phase the other group's MFMAs wait for.
+  const bf16_t* a_ptr[APASS];   // this lane's 16-byte piece of row j (or the zero block)
+  int a_inc[APASS];             // elements to move per chunk (0 for rows that read padding)
+  const bf16_t* w_ptr = p.w;    // the chunk's weight panel (wave-uniform)
+  const long w_inc = (long)p.Npad * HB_BK;
+  int ci_cur = 0;               // first channel of this lane's piece (only consulted when Cin % 32 != 0)
+  const bool cin_tail = (p.Cin & (HB_BK - 1)) != 0;
   int t_tap = -1;
+#pragma unroll
+  for (int j = 0; j < APASS; ++j) {
+    a_ptr[j] = zsrc;
+    a_inc[j] = 0;
+  }
   auto issue = [&](int tapi, int cb, auto bufc) {
     constexpr int buf = decltype(bufc)::value;
-    const bool past = tapi > last_tap;  // cursor ran past the end: harmless duplicate DMA into the idle buffer
-    const int cbb = past ? last_cb : cb;
-    if ((cb == 0 || t_tap < 0) && !past) {  // wave-uniform: a new tap begins (or a split starts inside one)
-      const int code = __builtin_amdgcn_readfirstlane(s_taps[tapi]);
-      const int r = (code >> 8) & 0xFF, s = code >> 16;
-      t_tap = code & 0xFF;
+    // (cursor past the end: the pointers stay on the last chunk -- a harmless duplicate DMA into the idle buffer)
+    if (tapi <= last_tap) {
+      if (cb == 0 || t_tap < 0) {  // wave-uniform: a new tap begins (or a split starts inside one)
+        const int code = __builtin_amdgcn_readfirstlane(s_taps[tapi]);
+        const int r = (code >> 8) & 0xFF, s = code >> 16;
+        t_tap = code & 0xFF;
+        ci_cur = cb * HB_BK + gq;
 #pragma unroll
-      for (int j = 0; j < APASS; ++j) {
-        const int nh = a_hy[j] + sgn * r, nw = a_wx[j] + sgn * s;
-        const int ih = nh >> sh, iw = nw >> sh;
-        t_ok[j] = a_ok[j] && nh >= 0 && nw >= 0 && ih < p.Hi && iw < p.Wi;
-        t_off[j] = t_ok[j] ? (long)(a_base[j] + ih * p.Wi + iw) * p.in_ld : 0L;
+        for (int j = 0; j < APASS; ++j) {
+          const int nh = a_hy[j] + sgn * r, nw = a_wx[j] + sgn * s;
+          const int ih = nh >> sh, iw = nw >> sh;
+          const bool ok = a_ok[j] && nh >= 0 && nw >= 0 && ih < p.Hi && iw < p.Wi;
+          a_ptr[j] = ok ? p.in + (long)(a_base[j] + ih * p.Wi + iw) * p.in_ld + ci_cur : zsrc;
+          a_inc[j] = ok ? HB_BK : 0;
+        }
+        w_ptr = p.w + ((long)t_tap * p.cpt + cb) * w_inc + (long)n0 * HB_BK;
+      } else {  // the next 32 channels of the same tap
+        ci_cur += HB_BK;
+#pragma unroll
+        for (int j = 0; j < APASS; ++j) a_ptr[j] += a_inc[j];
+        w_ptr += w_inc;
       }
     }
-    const int tap = t_tap < 0 ? 0 : t_tap;
-    const int ci = cbb * HB_BK + gq;
-    const bool cok = ci < p.Cin;
     bf16_t* dstA = bufp(buf);
 #pragma unroll
     for (int j = 0; j < APASS; ++j) {
-      const bool ok = t_ok[j] && cok;
-      const bf16_t* src = ok ? p.in + t_off[j] + ci : zsrc;
-      __builtin_amdgcn_global_load_lds((lich_gptr_t)src, (lich_lptr_t)(dstA + j * 2048 + wave * 512), 16, 0, 0);
+      const bf16_t* src = a_ptr[j];
+      if (cin_tail && ci_cur >= p.Cin) src = zsrc;  // (wave-uniform flag: Cin % 32 == 0 layers skip the compare)
+      // (A image: 64-byte rows in row order; a wave's 64 lanes cover 16 consecutive rows = 1 KiB)
+      bf16_t* da = (NWV == 8) ? dstA + 4096 * grp + 2048 * j + 512 * (wave & 3) : dstA + j * 2048 + wave * 512;
+      __builtin_amdgcn_global_load_lds((lich_gptr_t)src, (lich_lptr_t)da, 16, 0, 0);
     }
-    const bf16_t* wsrc = p.w + ((long)tap * p.cpt + cbb) * p.Npad * HB_BK + (long)n0 * HB_BK + tid * 8;
     bf16_t* dstB = dstA + BM * HB_BK;
 #pragma unroll
-    for (int j = 0; j < TN; ++j)
-      __builtin_amdgcn_global_load_lds((lich_gptr_t)(wsrc + j * 2048), (lich_lptr_t)(dstB + j * 2048 + wave * 512),
-                                       16, 0, 0);
+    for (int j = 0; j < BPASS; ++j) {
+      // 16-byte piece (j * NTH + tid) of the 256 TN pieces of the panel; past the end it wraps (wave-uniformly:
+      // the wrap is a multiple of 64 pieces) onto pieces that are loaded twice with the same bytes
+      int wv = j * NWV + wave;
+      if (wv * 64 >= 256 * TN) wv -= 4 * TN;
+      __builtin_amdgcn_global_load_lds((lich_gptr_t)(w_ptr + wv * 512 + lane * 8), (lich_lptr_t)(dstB + wv * 512), 16, 0, 0);
+    }
   };
   // A step reads ALL its fragments first (TM*2 + TW*2 ds_read_b128), then issues the next chunk's DMAs -- ~40
   // scalar / vector address instructions -- and only then runs the MFMAs: the LDS latency hides under the address
@@ -295,6 +336,42 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
     // chunk c, the barrier says everyone's landed and everyone finished reading chunk c-1, whose
     // buffer takes chunk c+RING-1 (past-the-end chunks are clamped duplicates, so the count is exact).
     static_assert(RING >= 3 && (RING - 2) * NL <= 63, "vmcnt is a 6-bit counter");
+    if constexpr (NWV == 8) {
+      auto load_phase = [&](auto cur) {
+        constexpr int CUR = decltype(cur)::value;
+        if (grp == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((RING - 2) * NL) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"i"((RING - 3) * NL) : "memory");
+        load_frags(cur);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(l_tap, l_cb, std::integral_constant<int, (CUR + RING - 1) % RING>{});
+        advance();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      };
+      auto chunk = [&](auto cur) {
+        load_phase(cur);
+        mfmas();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_barrier" ::: "memory");
+      };
+      lich_for_seq(std::make_integer_sequence<int, RING - 1>{}, [&](auto i) {
+        issue(l_tap, l_cb, i);
+        advance();
+      });
+      // group 0's first load phase reads the panel of chunk 0 before group 1 has had a load phase: group 1 waits
+      // for its share of chunk 0 here, then everyone meets
+      if (grp == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((RING - 2) * NL) : "memory");
+      asm volatile("s_barrier" ::: "memory");
+      // group 1 starts one phase late; group 0 idles one phase at the end: both execute 2 * nchunks + 2 barriers
+      if (grp == 1) asm volatile("s_barrier" ::: "memory");
+      int c = 0;
+      for (; c + RING - 1 < nchunks; c += RING) lich_for_seq(std::make_integer_sequence<int, RING>{}, chunk);
+      const int left = nchunks - c;
+      lich_for_seq(std::make_integer_sequence<int, RING>{}, [&](auto i) {
+        if (decltype(i)::value < left) chunk(i);
+      });
+      if (grp == 0) asm volatile("s_barrier" ::: "memory");
+    } else {
     auto step = [&](auto cur) {
       constexpr int CUR = decltype(cur)::value;
       asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"((RING - 2) * NL) : "memory");
@@ -316,6 +393,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_kernel(const IgemmHParams p) {
     lich_for_seq(std::make_integer_sequence<int, RING>{}, [&](auto i) {
       if (decltype(i)::value < left) step(i);
     });
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();  // the epilogue reuses the buffers
   }
@@ -697,10 +775,22 @@ static int igemmh_prepare(const lic_igemm_desc* d, int32_t out_f32, IgemmHParams
   p.NT = p.Npad / (64 * TN);
   BM = (((maxP + 127) / 128) * p.NT * p.nphase >= 512) ? 128 : 64;
   if (d->force_bm) {
-    if (d->force_bm != 64 && d->force_bm != 128) return LIC_ERR_UNSUPPORTED;
+    if (d->force_bm != 64 && d->force_bm != 128 && d->force_bm != 256) return LIC_ERR_UNSUPPORTED;
     BM = d->force_bm;
   }
   if (fuse) BM = 128;  // (the fused pool's wave layout)
+  // 256-row, 8-wave ping-pong variant (see the kernel): where it leaves at least one workgroup per CU
+  {
+    const char* e = getenv("LIC_BF16_PP");  // tuning aid: 0 = never
+    const bool off = e && e[0] == '0';
+    const long wgs256 = ((maxP + 255) / 256) * p.NT * p.nphase;
+    // (with the fused pool only for 192 channels: at 128 the 8x1 wave layout's fragment reads -- 80 KB of LDS per
+    // chunk -- made the 107-GFLOP layer 153 us against 135 on the 4-wave kernel, while at 192 the 4-wave fused
+    // variant runs at one wave per SIMD and the 8-wave one is 21 % faster)
+    const bool pays = !fuse || TN == 3;
+    if (p.prologue != 1 && ((d->force_bm == 256) || (!d->force_bm && !off && pays && wgs256 >= 256))) BM = 256;
+    else if (d->force_bm == 256) BM = 128;  // (the squaring prologue has no 8-wave variant)
+  }
   if (d->force_tn && d->force_tn != TN) return LIC_ERR_UNSUPPORTED;
   p.MT = (int)((maxP + BM - 1) / BM);
   p.pgroup = 0;
@@ -734,8 +824,8 @@ static int igemmh_prepare(const lic_igemm_desc* d, int32_t out_f32, IgemmHParams
     const bool simple = (epi == LIC_EPI_NONE || epi == LIC_EPI_LEAKY) && !d->out2 && d->prologue == 0;
     const long t_img = (((long)d->Ho * d->Wo + 63) / 64) * (p.Npad / 64);
     long S = 1;
-    if (simple && d->workspace && d->force_split != 1 && ((t_img < 4 && max_chunks >= 48) || d->force_split > 1) &&
-        max_chunks >= 2) {
+    if (simple && BM != 256 && d->workspace && d->force_split != 1 &&
+        ((t_img < 4 && max_chunks >= 48) || d->force_split > 1) && max_chunks >= 2) {
       S = (24 + t_img - 1) / t_img;
       if (S > max_chunks / 8) S = max_chunks / 8;  // at least 8 chunks (256 K) per split
       if (S > 32) S = 32;
@@ -757,7 +847,7 @@ static int igemmh_prepare(const lic_igemm_desc* d, int32_t out_f32, IgemmHParams
   if (nwg > 0x7FFFFFFFL) return LIC_ERR_UNSUPPORTED;
   {
     const char* e = getenv("LIC_BF16_RING");  // tuning aid: 3 = the three-buffer ring everywhere
-    p.ring = (BM == 128 && TN <= 2 && p.prologue != 1 && !(e && e[0] == '3')) ? 4 : 3;
+    p.ring = (BM == 256) ? 4 : ((BM == 128 && TN <= 2 && p.prologue != 1 && !(e && e[0] == '3')) ? 4 : 3);
   }
   return LIC_OK;
 }
@@ -789,8 +879,8 @@ LIC_EXPORT int lic_igemm_bf16_kernel_name(const lic_igemm_desc* d, char* buf, si
   if (!buf || n == 0) return LIC_ERR_INVALID;
   const bool fuse = p.epilogue == LIC_EPI_CONV_GDN || p.epilogue == LIC_EPI_CONV_IGDN;
   // (all five template arguments, as rocprofv3 prints them)
-  snprintf(buf, n, "igemm_bf16_kernel<%d, %d, %s, %s, %d>", BM, TN, p.prologue == 1 ? "true" : "false",
-           fuse ? "true" : "false", p.ring);
+  snprintf(buf, n, BM == 256 ? "igemm_bf16_kernel<%d, %d, %s, %s, %d, 8>" : "igemm_bf16_kernel<%d, %d, %s, %s, %d, 4>", BM, TN,
+           p.prologue == 1 ? "true" : "false", fuse ? "true" : "false", p.ring);
   return LIC_OK;
 }
 
@@ -804,6 +894,19 @@ LIC_EXPORT int lic_igemm_bf16(const lic_igemm_desc* d, int32_t out_f32, lic_stre
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)nwg), block(256);
   const bool fuse = p.epilogue == LIC_EPI_CONV_GDN || p.epilogue == LIC_EPI_CONV_IGDN;
+  if (BM == 256) {  // 8-wave ping-pong variant
+    dim3 block8(512);
+    if (fuse) {
+      if (TN == 3) hipLaunchKernelGGL((igemm_bf16_kernel<256, 3, false, true, 4, 8>), grid, block8, 0, s, p);
+      else if (TN == 2) hipLaunchKernelGGL((igemm_bf16_kernel<256, 2, false, true, 4, 8>), grid, block8, 0, s, p);
+      else hipLaunchKernelGGL((igemm_bf16_kernel<256, 1, false, true, 4, 8>), grid, block8, 0, s, p);
+    } else {
+      if (TN == 3) hipLaunchKernelGGL((igemm_bf16_kernel<256, 3, false, false, 4, 8>), grid, block8, 0, s, p);
+      else if (TN == 2) hipLaunchKernelGGL((igemm_bf16_kernel<256, 2, false, false, 4, 8>), grid, block8, 0, s, p);
+      else hipLaunchKernelGGL((igemm_bf16_kernel<256, 1, false, false, 4, 8>), grid, block8, 0, s, p);
+    }
+    return lic_check_launch();
+  }
 #define LIC_IGEMMH_LAUNCH(bm, tn)                                                           \
   do {                                                                                      \
     constexpr int R4 = (tn <= 2) ? 4 : 3; /* the ring p.ring asks for on 128-row tiles */   \

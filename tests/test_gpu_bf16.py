@@ -79,6 +79,37 @@ def test_conv_bf16_ops(env, k, s, p, ci, co, H, W, B, tr, op, split):
         F_.FORCE_IGEMM = None
 
 
+@pytest.mark.parametrize("k,s,p,ci,co,H,W,B,tr,op", [(5, 2, 2, 64, 64, 40, 36, 2, False, 0),     # 720 rows: 2.8 tiles
+                                                     (5, 2, 2, 128, 128, 34, 30, 1, False, 0),
+                                                     (3, 1, 1, 72, 192, 20, 20, 1, False, 0),    # K tail, 192 columns
+                                                     (5, 2, 2, 128, 64, 13, 11, 2, True, 1),     # 4 phases, ragged
+                                                     (5, 2, 2, 64, 192, 12, 12, 1, True, 1),
+                                                     (1, 1, 0, 192, 128, 17, 19, 1, False, 0)])
+def test_conv_bf16_ops_eight_wave_tile(env, k, s, p, ci, co, H, W, B, tr, op):
+    """the 256-row, 8-wave ping-pong variant (what the big layers dispatch) forced onto small ragged shapes: against
+    the oracle, and bitwise against the 4-wave kernel (same chunk and k order per output)"""
+    nic, FB, O, d = env
+    from neural_image_compression_amd import functional as F_
+    names = set()
+    F_.FORCE_IGEMM, F_.KERNEL_TRACE = (256, 0, 1), names
+    try:
+        _conv_bf16_ops(env, k, s, p, ci, co, H, W, B, tr, op)
+        r = np.random.RandomState(ci + co)
+        x = dev(rb(r.randn(B, ci, H, W).astype(np.float32)), d, BF)
+        wshape = (ci, co, k, k) if tr else (co, ci, k, k)
+        w = dev(rb((r.randn(*wshape) / math.sqrt(ci * k * k)).astype(np.float32)), d).contiguous()
+        b = dev(r.randn(co).astype(np.float32), d)
+        f = (lambda: FB.conv_transpose2d_bf16(x, w, b, s, p, op)) if tr else (lambda: FB.conv2d_bf16(x, w, b, s, p))
+        with torch.no_grad():
+            y8 = f()
+            F_.FORCE_IGEMM = (128, 0, 1)
+            y4 = f()
+    finally:
+        F_.FORCE_IGEMM, F_.KERNEL_TRACE = None, None
+    assert any(n.startswith("igemm_bf16_kernel<256,") and n.endswith(", 8>") for n in names), names
+    assert torch.equal(y8, y4)
+
+
 def test_conv_bf16_split_is_batch_invariant(env):
     """the K split is chosen from per-image geometry: an image's output bits do not depend on its batch"""
     nic, FB, O, d = env
@@ -197,6 +228,9 @@ def test_gdn_bf16(env, inverse):
     (5, 2, 2, 3, 64, 21, 19, 3, False, 0, False, 64),     # odd sizes: every border case of the window loads
     (5, 2, 2, 3, 128, 96, 80, 3, False, 0, False, 128),   # 45 tiles: the persistent loop
     (3, 2, 1, 3, 128, 12, 12, 2, False, 0, False, 128),   # a stem the direct kernel does not cover: columns + GEMM
+    (5, 2, 2, 64, 128, 40, 36, 2, False, 0, False, 256),  # the 8-wave ping-pong tile with the fused pool
+    (5, 2, 2, 128, 192, 18, 22, 1, False, 0, False, 256),
+    (5, 2, 2, 64, 64, 13, 11, 2, True, 1, True, 256),     # ... transposed, 4 phases, IGDN
 ])
 def test_conv_gdn_fused_bf16_matches_two_launches(env, k, s, p, ci, co, H, W, B, tr, op, inverse, bm):
     nic, FB, O, d = env
@@ -249,7 +283,7 @@ def test_conv_gdn_fused_bf16_matches_two_launches(env, k, s, p, ci, co, H, W, B,
     if stem and (k, s, p) == (5, 2, 2):
         assert f"stem_gdn_bf16_kernel<{co // 32}, {8 if co == 192 else 4}>" in names, names
     else:
-        assert any(n.startswith(f"igemm_bf16_kernel<128, {tn}, false, true") for n in names), names
+        assert any(n.startswith(f"igemm_bf16_kernel<{256 if bm == 256 else 128}, {tn}, false, true") for n in names), names
     whats = ["y"] + ([] if stem else ["dx"]) + ["dw", "db", "dbeta", "dgamma"]
     # y: at most one bf16 ulp apart (an ulp is 2^-8 .. 2^-7 of the value); the direct stem also sums its 75 products
     # in another order than the column GEMM, so its conv output can itself sit one ulp away
