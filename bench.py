@@ -24,6 +24,7 @@ from __future__ import annotations
 
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -246,6 +247,17 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     el = float(t.item())
 
+    # a throughput number over arithmetic that went wrong is not a measurement: a non-finite loss after the timed
+    # steps (a race in a kernel once showed up ONLY here, as NaNs in the two-stream step) fails the run loudly
+    final_loss = float(res["loss"].detach())
+    ok = torch.tensor([1.0 if math.isfinite(final_loss) else 0.0], device=dev)
+    if world > 1:
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)   # (every rank leaves together)
+    if float(ok.item()) == 0.0:
+        if world > 1 or force_red:
+            dist.destroy_process_group()
+        raise SystemExit(f"bench.py: the loss after {args.warmup + args.steps} steps is {final_loss} -- refusing to report "
+                         "a throughput for a diverged / corrupted run")
     if rank == 0:
         ms = el / args.steps * 1e3
         value = world * B * args.steps / el

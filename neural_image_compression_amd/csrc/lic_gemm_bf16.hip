@@ -97,10 +97,9 @@ __device__ __forceinline__ void lich_for_seq(std::integer_sequence<int, Is...>, 
 // after each -- while one group's waves occupy the matrix pipe the other group's do their LDS / address / DMA
 // work on the same SIMDs, instead of two independent workgroups colliding at random (PMC of the 4-wave kernel on
 // the 107-GFLOP layer: 37 % of wave cycles parked, 35 % issue-stalled).  Group g DMAs only its own 128 rows of A
-// (no cross-group dependency there) and half the weight panel; a wave of group 1 therefore waits one chunk
-// further than it needs itself (vmcnt(NL) instead of vmcnt(2 NL)), so that its share of chunk c's panel has
-// landed before the barrier in front of group 0's read of it.  A buffer is refilled only after both groups waited
-// lgkmcnt(0) on their reads of it and passed a barrier.  Same chunk and k order per output as the 4-wave
+// and half the weight panel.  Every load phase ends with the wave's wait for its DMAs of the NEXT chunk and the
+// barrier, so a chunk is read one phase after the wait that retires it, whichever wave loaded the piece; a buffer is
+// refilled only after both groups waited lgkmcnt(0) on their reads of it and passed a barrier.  Same chunk and k order per output as the 4-wave
 // kernel: the results are bitwise the same.
 template <int BM, int TN, bool SQ = false, bool FUSE = false, int RING = 3, int NWV = 4>
 __global__ __launch_bounds__(64 * NWV) void igemm_bf16_kernel(const IgemmHParams p) {
@@ -337,16 +336,20 @@ __global__ __launch_bounds__(64 * NWV) void igemm_bf16_kernel(const IgemmHParams
     // buffer takes chunk c+RING-1 (past-the-end chunks are clamped duplicates, so the count is exact).
     static_assert(RING >= 3 && (RING - 2) * NL <= 63, "vmcnt is a 6-bit counter");
     if constexpr (NWV == 8) {
+      // A chunk is read one phase AFTER the wait that retires it: every wave ends its load phase of chunk c by
+      // waiting for its own DMAs of chunk c+1 (vmcnt leaves the two youngest chunks, c+2 and c+3, in flight) and
+      // then passes the barrier -- so when either group starts reading chunk c+1, all eight waves' pieces of it
+      // (a wave reads rows and panel pieces that OTHER waves loaded) have landed.  Waiting at the START of the
+      // load phase instead, after the barrier, orders only a wave's own pieces: that version passed every
+      // small test and produced NaNs in the two-stream training step.
       auto load_phase = [&](auto cur) {
         constexpr int CUR = decltype(cur)::value;
-        if (grp == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((RING - 2) * NL) : "memory");
-        else asm volatile("s_waitcnt vmcnt(%0)" ::"i"((RING - 3) * NL) : "memory");
         load_frags(cur);
         __builtin_amdgcn_sched_barrier(0);
         issue(l_tap, l_cb, std::integral_constant<int, (CUR + RING - 1) % RING>{});
         advance();
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"i"((RING - 2) * NL) : "memory");
       };
       auto chunk = [&](auto cur) {
         load_phase(cur);
@@ -358,10 +361,8 @@ __global__ __launch_bounds__(64 * NWV) void igemm_bf16_kernel(const IgemmHParams
         issue(l_tap, l_cb, i);
         advance();
       });
-      // group 0's first load phase reads the panel of chunk 0 before group 1 has had a load phase: group 1 waits
-      // for its share of chunk 0 here, then everyone meets
-      if (grp == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"i"((RING - 2) * NL) : "memory");
-      asm volatile("s_barrier" ::: "memory");
+      // chunk 0 has landed for everyone before the first load phase
+      asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"((RING - 2) * NL) : "memory");
       // group 1 starts one phase late; group 0 idles one phase at the end: both execute 2 * nchunks + 2 barriers
       if (grp == 1) asm volatile("s_barrier" ::: "memory");
       int c = 0;
@@ -562,7 +563,8 @@ __global__ __launch_bounds__(64 * NWV) void igemm_bf16_kernel(const IgemmHParams
           for (int e = 0; e < 8; ++e) {
             const float nf = (float)n[e];
             const float f = (epi == LIC_EPI_GDN_BWD) ? __builtin_amdgcn_rsqf(nf) : __builtin_amdgcn_sqrtf(nf);
-            v[e] = (float)g[e] * f + 2.0f * (float)x[e] * v[e];
+            // (explicit fma: left to the compiler, the 4- and 8-wave instantiations contracted this differently)
+            v[e] = __builtin_fmaf(2.0f * (float)x[e], v[e], (float)g[e] * f);
           }
         }
         if (of32) {
@@ -784,10 +786,11 @@ static int igemmh_prepare(const lic_igemm_desc* d, int32_t out_f32, IgemmHParams
     const char* e = getenv("LIC_BF16_PP");  // tuning aid: 0 = never
     const bool off = e && e[0] == '0';
     const long wgs256 = ((maxP + 255) / 256) * p.NT * p.nphase;
-    // (with the fused pool only for 192 channels: at 128 the 8x1 wave layout's fragment reads -- 80 KB of LDS per
-    // chunk -- made the 107-GFLOP layer 153 us against 135 on the 4-wave kernel, while at 192 the 4-wave fused
-    // variant runs at one wave per SIMD and the 8-wave one is 21 % faster)
-    const bool pays = !fuse || TN == 3;
+    // Where it pays (measured with the final, race-free hand-over; same box, two runs each): 192-channel layers --
+    // config 2h 4720-4760 -> 4980-5000 img/s, the fused-pool launch 344 -> 270 us (the 4-wave fused variant is
+    // stuck at one wave per SIMD there) -- but NOT 128-channel ones: config 3 7400 -> 7180 img/s, and the
+    // fused 8x1 layout 135 -> 153 us (80 KB of fragment reads per chunk).
+    const bool pays = TN == 3;
     if (p.prologue != 1 && ((d->force_bm == 256) || (!d->force_bm && !off && pays && wgs256 >= 256))) BM = 256;
     else if (d->force_bm == 256) BM = 128;  // (the squaring prologue has no 8-wave variant)
   }

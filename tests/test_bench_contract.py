@@ -25,6 +25,7 @@ def check_line(d, want_cpu):
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["data"] == "synthetic"
     assert d["unit"] == "images/s" and d["value"] > 0
     assert "workload" in d["config"] and "model" not in d["config"]
+    assert d["config"]["loss"] == d["config"]["loss"] and abs(d["config"]["loss"]) < 1e6, "non-finite loss in a bench line"
     assert abs(d["value"] - d["config"]["global_batch"] / d["ms_per_step"] * 1e3) <= 0.01 * d["value"]
     r = d["roofline"]
     for k, t in ROOFLINE.items():

@@ -110,6 +110,40 @@ def test_conv_bf16_ops_eight_wave_tile(env, k, s, p, ci, co, H, W, B, tr, op):
     assert torch.equal(y8, y4)
 
 
+def test_eight_wave_tile_at_full_size_beside_a_second_stream(env):
+    """The 8-wave variant's groups hand chunks to each other through counted waits and barriers; a mistake there is
+    a RACE that small quiet launches never lose (an early version passed everything above and produced NaNs only in
+    the two-stream training step).  So: the real 128 -> 128, 5x5 s2 layer of config 3 (128 tiles per XCD) and its
+    transposed twin, while a second stream keeps the GPU busy with other work, several times, bitwise against the
+    4-wave kernel."""
+    nic, FB, O, d = env
+    from neural_image_compression_amd import functional as F_
+    g = torch.Generator(device="cpu").manual_seed(5)
+    x = torch.randn(32, 128, 128, 128, generator=g).to(d).contiguous(memory_format=torch.channels_last).to(BF)
+    xs = torch.randn(32, 128, 64, 64, generator=g).to(d).contiguous(memory_format=torch.channels_last).to(BF)
+    w = (torch.randn(128, 128, 5, 5, generator=g) / 56.0).to(d)
+    b = torch.randn(128, generator=g).to(d)
+    a = torch.randn(4096, 4096, device=d, dtype=BF)
+    side = torch.cuda.Stream()
+    fns = [lambda: FB.conv2d_bf16(x, w, b, 2, 2), lambda: FB.conv_transpose2d_bf16(xs, w, b, 2, 2, 1)]
+    with torch.no_grad():
+        F_.FORCE_IGEMM = (128, 0, 1)
+        try:
+            ref = [f() for f in fns]
+            torch.cuda.synchronize()
+            F_.FORCE_IGEMM = (256, 0, 1)
+            for it in range(6):
+                with torch.cuda.stream(side):
+                    for _ in range(6):
+                        a @ a
+                outs = [f() for f in fns]
+                torch.cuda.synchronize()
+                for o, r_ in zip(outs, ref):
+                    assert torch.equal(o, r_), f"iteration {it}: the 8-wave tile differs from the 4-wave kernel"
+        finally:
+            F_.FORCE_IGEMM = None
+
+
 def test_conv_bf16_split_is_batch_invariant(env):
     """the K split is chosen from per-image geometry: an image's output bits do not depend on its batch"""
     nic, FB, O, d = env
