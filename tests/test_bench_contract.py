@@ -84,7 +84,7 @@ def test_live_bench_line():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cfg", ["3", "2h"])
+@pytest.mark.parametrize("cfg", ["2", "3", "2h"])
 def test_two_stream_training_step_is_finite_and_repeatable(cfg):
     """The whole two-stream training step (every kernel variant the config dispatches, at full size, beside each
     other) run twice from the same seed: the loss after the steps is finite and bit-identical.  This is the net that
