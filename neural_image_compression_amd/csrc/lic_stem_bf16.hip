@@ -50,7 +50,8 @@ __device__ __forceinline__ unsigned pack2(f32x2 v) {
 
 // TW: 32-channel tiles (C = 32*TW); NW: waves per workgroup (tile = 32*NW pixels).
 // (C = 128 compiles to 184 VGPR + 64 AGPR: two waves per SIMD.  Forced to three -- 168 registers, 60 bytes of
-// scratch -- it ran 100 us instead of 72 at config 3.)
+// scratch -- it ran 100 us instead of 72 at config 3.  Issuing the NEXT tile's window loads under the current
+// tile's epilogue keeps 40 more registers live: one wave per SIMD, 94 us.  Neither kept.)
 template <int TW, int NW>
 __global__ __launch_bounds__(64 * NW) void stem_gdn_bf16_kernel(const StemParams p) {
   constexpr int C = 32 * TW;
