@@ -53,6 +53,7 @@ struct IgemmHParams {
   float* slabs;     // [ksplit][B*Ho*Wo][Cout]
   int ring;         // host side only: the RING template argument of the launch
   int pgroup, porder;  // 4-phase launches: phase-sorted groups of `pgroup` M tiles, order 2 bits per rank
+  int htx, hty;        // halo-resident variant (lic_halo_bf16.h): output tiles per image along x / y
   int ntaps[4];
   int Hq[4], Wq[4];
   FastDivB dHW[4], dW[4];
@@ -628,6 +629,13 @@ __global__ __launch_bounds__(256) void igemm_bf16_finish_kernel(const float* sla
   }
 }
 
+#include "lic_halo_bf16.h"
+
+#ifdef LIC_HALO_ABLATE
+LIC_EXPORT int lic_halo_debug_read(void* dst, size_t bytes) {
+  return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(g_halo_dbg), bytes);
+}
+#endif
 static bool al16h(const void* q) { return q == nullptr || (reinterpret_cast<uintptr_t>(q) & 15) == 0; }
 
 LIC_EXPORT int lic_igemm_bf16_fused_gdn_supported(int32_t Cin, int32_t Cout) {
@@ -777,8 +785,8 @@ static int igemmh_prepare(const lic_igemm_desc* d, int32_t out_f32, IgemmHParams
   p.NT = p.Npad / (64 * TN);
   BM = (((maxP + 127) / 128) * p.NT * p.nphase >= 512) ? 128 : 64;
   if (d->force_bm) {
-    if (d->force_bm != 64 && d->force_bm != 128 && d->force_bm != 256) return LIC_ERR_UNSUPPORTED;
-    BM = d->force_bm;
+    if (d->force_bm != 64 && d->force_bm != 128 && d->force_bm != 256 && d->force_bm != 512) return LIC_ERR_UNSUPPORTED;
+    if (d->force_bm != 512) BM = d->force_bm;
   }
   if (fuse) BM = 128;  // (the fused pool's wave layout)
   // 256-row, 8-wave ping-pong variant (see the kernel): where it leaves at least one workgroup per CU
@@ -793,6 +801,36 @@ static int igemmh_prepare(const lic_igemm_desc* d, int32_t out_f32, IgemmHParams
     const bool pays = TN == 3;
     if (p.prologue != 1 && ((d->force_bm == 256) || (!d->force_bm && !off && pays && wgs256 >= 256))) BM = 256;
     else if (d->force_bm == 256) BM = 128;  // (the squaring prologue has no 8-wave variant)
+  }
+  // Halo-resident variant (lic_halo_bf16.h; BM = 512 names it): the 5x5 stride-2 layers of the analysis / synthesis
+  // stacks (Components.py:12,14,41,43 -- forward convolutions and the data gradients of the transposed ones) with
+  // 128 output channels, when the launch has at least half a workgroup per CU.  force_bm = 512 forces it on every
+  // launch it covers (parity tests on small shapes; other launches keep their automatic tile), any other force_bm
+  // and LIC_BF16_HALO=0 keep the implicit-GEMM tiles.
+  p.htx = p.hty = 0;
+  {
+    const bool shape_ok = !p.transposed && d->kh == 5 && d->kw == 5 && d->stride == 2 && d->pad == 2 &&
+                          (d->tap_mask == 0 || (d->tap_mask & 0x1FFFFFFu) == 0x1FFFFFFu) && d->prologue == 0 &&
+                          (epi == LIC_EPI_NONE || epi == LIC_EPI_LEAKY) && !d->out2 && d->Cin % 64 == 0 &&
+                          d->Cout == 128 && d->Ho == (d->Hi - 1) / 2 + 1 &&
+                          d->Wo == (d->Wi - 1) / 2 + 1 && (long)d->B * d->Hi * d->Wi * d->in_ld < 0x7FFFFFFFL;
+    const int htx = (d->Wo + halo::TWD - 1) / halo::TWD, hty = (d->Ho + halo::TH - 1) / halo::TH;
+    const char* e = getenv("LIC_BF16_HALO");  // tuning aid: 0 = never
+    const bool off = e && e[0] == '0';
+    if (shape_ok && (d->force_bm == 512 || (!d->force_bm && !off && (long)d->B * htx * hty >= 128))) {
+      BM = 512;
+      p.htx = htx;
+      p.hty = hty;
+      p.MT = d->B * htx * hty;
+      p.NT = 1;
+      p.pgroup = p.porder = 0;
+      p.ksplit = 1;
+      p.cps = 0;
+      p.slabs = nullptr;
+      p.ring = 0;
+      nwg = p.MT;
+      return LIC_OK;
+    }
   }
   if (d->force_tn && d->force_tn != TN) return LIC_ERR_UNSUPPORTED;
   p.MT = (int)((maxP + BM - 1) / BM);
@@ -880,6 +918,10 @@ LIC_EXPORT int lic_igemm_bf16_kernel_name(const lic_igemm_desc* d, char* buf, si
   const int rc = igemmh_prepare(d, 0, p, BM, TN, nwg);
   if (rc < 0) return rc;
   if (!buf || n == 0) return LIC_ERR_INVALID;
+  if (BM == 512) {
+    snprintf(buf, n, "halo_conv_bf16_kernel<%d>", p.Npad / 64);
+    return LIC_OK;
+  }
   const bool fuse = p.epilogue == LIC_EPI_CONV_GDN || p.epilogue == LIC_EPI_CONV_IGDN;
   // (all five template arguments, as rocprofv3 prints them)
   snprintf(buf, n, BM == 256 ? "igemm_bf16_kernel<%d, %d, %s, %s, %d, 8>" : "igemm_bf16_kernel<%d, %d, %s, %s, %d, 4>", BM, TN,
@@ -897,6 +939,31 @@ LIC_EXPORT int lic_igemm_bf16(const lic_igemm_desc* d, int32_t out_f32, lic_stre
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)nwg), block(256);
   const bool fuse = p.epilogue == LIC_EPI_CONV_GDN || p.epilogue == LIC_EPI_CONV_IGDN;
+  if (BM == 512) {  // halo-resident 5x5 stride-2 variant: persistent workgroups, one per CU
+    static int ncu = 0;
+    if (!ncu) {
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+        n = 256;
+      ncu = n;
+    }
+    grid = dim3((unsigned)(nwg < ncu ? nwg : ncu));
+#ifdef LIC_HALO_ABLATE
+    if (const char* e = getenv("LIC_HALO_ABL")) {
+      const int a = atoi(e);
+      if (a == 1) hipLaunchKernelGGL((halo_conv_bf16_kernel<2, 1>), grid, block, 0, s, p);
+      if (a == 2) hipLaunchKernelGGL((halo_conv_bf16_kernel<2, 2>), grid, block, 0, s, p);
+      if (a == 4) hipLaunchKernelGGL((halo_conv_bf16_kernel<2, 4>), grid, block, 0, s, p);
+      if (a == 3) hipLaunchKernelGGL((halo_conv_bf16_kernel<2, 3>), grid, block, 0, s, p);
+      if (a == 7) hipLaunchKernelGGL((halo_conv_bf16_kernel<2, 7>), grid, block, 0, s, p);
+      if (a) return lic_check_launch();
+    }
+#endif
+    // (a 192-channel instance, 128 x 96 per wave, compiles but needs more than the 256 + 256 registers: hipcc moves
+    // fragments that are still in flight; not dispatched)
+    hipLaunchKernelGGL((halo_conv_bf16_kernel<2>), grid, block, 0, s, p);
+    return lic_check_launch();
+  }
   if (BM == 256) {  // 8-wave ping-pong variant
     dim3 block8(512);
     if (fuse) {

@@ -144,6 +144,69 @@ def test_eight_wave_tile_at_full_size_beside_a_second_stream(env):
             F_.FORCE_IGEMM = None
 
 
+@pytest.mark.parametrize("ci,co,H,W,B", [(64, 128, 37, 45, 2),     # partial tiles in both directions, 2 chunks
+                                          (128, 128, 20, 70, 1),    # two column tiles, the second 3 pixels wide
+                                          (192, 128, 16, 16, 3),    # 6 chunks (three trips of the two-chunk body)
+                                          (64, 128, 5, 3, 2)])      # a tile that is almost all padding
+def test_halo_conv_forced_onto_small_ragged_shapes(env, ci, co, H, W, B):
+    """the halo-resident 5x5 stride-2 kernel (lic_halo_bf16.h; what the 128-channel stride-2 layers of config 3
+    dispatch at full size) forced onto small ragged shapes, forward and backward against the oracle"""
+    nic, FB, O, d = env
+    from neural_image_compression_amd import functional as F_
+    names = set()
+    F_.FORCE_IGEMM, F_.KERNEL_TRACE = (512, 0, 1), names
+    try:
+        _conv_bf16_ops(env, 5, 2, 2, ci, co, H, W, B, False, 0)
+    finally:
+        F_.FORCE_IGEMM, F_.KERNEL_TRACE = None, None
+    assert "halo_conv_bf16_kernel<2>" in names, names
+
+
+def test_halo_conv_at_full_size_beside_a_second_stream(env):
+    """The halo kernel hands LDS buffers from the DMA to the fragment reads with counted `vmcnt` waits and ONE barrier
+    per channel chunk, and keeps weight fragments in flight in registers: a mistake there is a race that small quiet
+    launches never lose.  The real 128 -> 128 stride-2 layer of config 3 at batch 32 (two tiles per persistent
+    workgroup: the cross-tile prefetch runs), picked by the AUTOMATIC dispatch, beside a busy second stream, four
+    rounds: equal to the implicit-GEMM tile within fp32 summation order (the K order differs: chunk-major), and
+    bit-identical from launch to launch; also with the fused LeakyReLU and an fp32 output."""
+    nic, FB, O, d = env
+    from neural_image_compression_amd import functional as F_
+    g = torch.Generator(device="cpu").manual_seed(11)
+    x = torch.randn(32, 128, 128, 128, generator=g).to(d).contiguous(memory_format=torch.channels_last).to(BF)
+    w = (torch.randn(128, 128, 5, 5, generator=g) / 56.0).to(d)
+    b = torch.randn(128, generator=g).to(d)
+    a = torch.randn(4096, 4096, device=d, dtype=BF)
+    side = torch.cuda.Stream()
+    fns = [lambda: FB.conv2d_bf16(x, w, b, 2, 2), lambda: FB.conv2d_bf16(x, w, b, 2, 2, leaky=True, slope=0.01),
+           lambda: FB.conv2d_bf16(x, w, b, 2, 2, out_f32=True)]
+    names = set()
+    with torch.no_grad():
+        F_.FORCE_IGEMM = (128, 0, 1)
+        try:
+            ref = [f().float() for f in fns]
+            torch.cuda.synchronize()
+            F_.FORCE_IGEMM, F_.KERNEL_TRACE = None, names
+            first = None
+            for it in range(4):
+                with torch.cuda.stream(side):
+                    for _ in range(6):
+                        a @ a
+                outs = [f() for f in fns]
+                torch.cuda.synchronize()
+                for o, r_ in zip(outs, ref):
+                    err = (o.float() - r_).abs()
+                    tol = 2.0 ** -7 * r_.abs() + 2.0 ** -7 * 1e-2 * r_.abs().max()   # one bf16 ulp either way
+                    assert bool((err <= tol).all()), f"iteration {it}: {float(err.max()):.3e}"
+                if first is None:
+                    first = outs
+                else:
+                    for o, f0 in zip(outs, first):
+                        assert torch.equal(o, f0), f"iteration {it}: the halo kernel is not bit-repeatable"
+        finally:
+            F_.FORCE_IGEMM, F_.KERNEL_TRACE = None, None
+    assert names == {"halo_conv_bf16_kernel<2>"}, names
+
+
 def test_conv_bf16_split_is_batch_invariant(env):
     """the K split is chosen from per-image geometry: an image's output bits do not depend on its batch"""
     nic, FB, O, d = env
