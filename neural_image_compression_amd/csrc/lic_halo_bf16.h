@@ -102,9 +102,13 @@ __global__ __launch_bounds__(256, 1) void halo_conv_bf16_kernel(const IgemmHPara
 
   // ---- halo DMA: piece (4 j + wave) of a buffer = LDS bytes [1024 (4 j + wave), +1024); lane -> 16-byte slot
   // n = 64 (4 j + wave) + lane = (plane-linear pixel n >> 2, physical octet n & 3).  Tile-independent per lane:
-  // rel[j] = element offset of the slot's source from the halo origin; meta[j >> 1] packs, 16 bits per piece, the
-  // slot's halo row (5 bits) | column << 5 (7 bits) | pad << 15
-  int rel[NPIECE];
+  // rel[j] = BYTE offset of the slot's source from the halo origin; meta[j >> 1] packs, 16 bits per piece, the
+  // slot's halo row (5 bits) | column << 5 (7 bits) | pad << 15.  The pieces are `buffer_load_dwordx4 ... lds` on a
+  // descriptor whose base is the tile's halo origin: a lane whose slot lies outside the image gets an offset past
+  // num_records and the hardware writes zeros without touching memory -- per piece that is 3 VALU + the load,
+  // where a flat address with a zero-page select took a dozen scalar / vector instructions (the pieces cost 17 %
+  // of the loop's cycles that way: in-kernel stamps with and without them).
+  unsigned rel[NPIECE];
   unsigned meta[NPIECE / 2];
 #pragma unroll
   for (int j = 0; j < NPIECE; ++j) {
@@ -116,14 +120,14 @@ __global__ __launch_bounds__(256, 1) void halo_conv_bf16_kernel(const IgemmHPara
     const int hc = pl ? Pp - hr * WP1 : Pp - hr * WP0;
     const int o = slot ^ ((hc >> 2) & 3);
     const int col = 2 * hc + pl;
-    rel[j] = (hr * p.Wi + col) * (int)p.in_ld + o * 8;
+    rel[j] = 2u * (unsigned)((hr * p.Wi + col) * (int)p.in_ld + o * 8);
     const unsigned m = (unsigned)(hr & 31) | ((unsigned)col << 5) | (hr < HR ? 0u : 0x8000u);
     if (j & 1) meta[j >> 1] |= m << 16;
     else meta[j >> 1] = m;
   }
   struct Geo {
     int b, oy0, ox0;
-    long base;      // element offset of the halo origin (may lie before the image: masked pieces are never fetched)
+    long base;      // element offset of the halo origin (may lie before the image: masked lanes never fetch)
     unsigned vmask; // bit j: piece j of this lane reads the image (else the zero page)
   };
   auto geom = [&](int t) {
@@ -150,13 +154,17 @@ __global__ __launch_bounds__(256, 1) void halo_conv_bf16_kernel(const IgemmHPara
     g.vmask = vm;
     return g;
   };
-  const bf16_t* zsrc = reinterpret_cast<const bf16_t*>(g_lic_zero16h);
   const int nch = p.cpt;  // 32-channel chunks (even)
-  // `base`: wave-uniform element offset of (tile halo origin, channel chunk); vm = 0: zero-page duplicates into the
-  // idle buffer (past the last tile) keep the vmcnt arithmetic exact
-  auto dma_piece = [&](int j, long base, unsigned vm, int buf) {
-    const bf16_t* src = ((vm >> j) & 1u) ? p.in + base + rel[j] : zsrc;
-    __builtin_amdgcn_global_load_lds((lich_gptr_t)src, (lich_lptr_t)(smem + buf * BUFB + (j * 4 + wave) * 1024), 16, 0, 0);
+  constexpr unsigned OOB = 0xFFFFFFF0u, NREC = 0x7FFFFFF0u;
+  auto halo_rsrc = [&](long base) {  // (wave-uniform by construction: kernel arguments and the tile index)
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16_t*>(p.in + base), 0, NREC, 0x00020000);
+  };
+  // soff: byte offset of the channel chunk; vm = 0 (past the last tile): every lane out of range, zeros into the
+  // idle buffer, which keeps the vmcnt arithmetic exact
+  auto dma_piece = [&](int j, __amdgpu_buffer_rsrc_t rs, int soff, unsigned vm, int buf) {
+    const unsigned off = ((vm >> j) & 1u) ? rel[j] : OOB;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lich_lptr_t)(smem + buf * BUFB + (j * 4 + wave) * 1024), 16, (int)off, soff,
+                                             0, 0);
   };
 
   // ---- A fragment addresses: lane (li, lh) of row tile a reads pixel (row 2 (4 wm + a) + r, column li + (s >> 1)) of
@@ -240,9 +248,9 @@ __global__ __launch_bounds__(256, 1) void halo_conv_bf16_kernel(const IgemmHPara
   // One tap: U = tap index inside the two-chunk loop body (0..49); U / 25 = halo buffer = chunk parity.
   //   wait -> (tap 24: chunk barrier) -> [MFMA i | one piece of the tap's other work] x NM
   // other work, in issue order: the 8 A reads of the NEXT tap (into the A slot tap U-1 used), the NB weight loads of
-  // tap U + D-1 (into the set tap U-1 used) and the pointer step, then this tap's halo DMA pieces (dbase / dvm: the
-  // chunk after this one -- of this tile, of the next tile, or nothing).
-  auto tap_step = [&](auto uc, int c, long dbase, unsigned dvm) {
+  // tap U + D-1 (into the set tap U-1 used) and the pointer step, then this tap's halo DMA pieces (drs / dsoff / dvm:
+  // the chunk after this one -- of this tile, of the next tile, or nothing).
+  auto tap_step = [&](auto uc, int c, __amdgpu_buffer_rsrc_t drs, int dsoff, unsigned dvm) {
     constexpr int U = decltype(uc)::value, T = U % NTAP, BUF = U / NTAP;
     constexpr int SA = U & 1, SB = U % D;
     constexpr int UN = (U + 1) % (2 * NTAP), TN1 = UN % NTAP, BUFN = UN / NTAP;  // the next tap
@@ -276,7 +284,7 @@ __global__ __launch_bounds__(256, 1) void halo_conv_bf16_kernel(const IgemmHPara
           bptr += tap_inc;
         }
       } else if constexpr (I < 8 + NB + 1 + np(T)) {
-        if constexpr (!(ABL & 4)) dma_piece(2 * T + (I - 8 - NB - 1), dbase, dvm, 1 - BUF);
+        if constexpr (!(ABL & 4)) dma_piece(2 * T + (I - 8 - NB - 1), drs, dsoff, dvm, 1 - BUF);
       }
       __builtin_amdgcn_sched_barrier(0);
     });
@@ -284,8 +292,11 @@ __global__ __launch_bounds__(256, 1) void halo_conv_bf16_kernel(const IgemmHPara
 
   // ---- prologue (first tile only): the weight sets of taps 0..D-2, chunk 0 into buffer 0, then tap 0's A fragments
   Geo cur = geom(tile);
+  {
+    const __amdgpu_buffer_rsrc_t rs0 = halo_rsrc(cur.base);
 #pragma unroll
-  for (int j = 0; j < NPIECE; ++j) dma_piece(j, cur.base, cur.vmask, 0);
+    for (int j = 0; j < NPIECE; ++j) dma_piece(j, rs0, 0, cur.vmask, 0);
+  }
   bptr += 2048;  // (the loads address [-2048, +3072] around the pointer: 13-bit signed immediates)
   lich_for_seq(std::make_integer_sequence<int, D - 1>{}, [&](auto sc) {
     lich_for_seq(std::make_integer_sequence<int, NB>{}, [&](auto ic) { b_load1(sc, ic); });
@@ -315,12 +326,13 @@ __global__ __launch_bounds__(256, 1) void halo_conv_bf16_kernel(const IgemmHPara
     for (int c0 = 0; c0 < nch; c0 += 2) {
       // chunk c0 fetches chunk c0 + 1 of this tile; chunk c0 + 1 fetches chunk c0 + 2, or the next tile's first
       const bool last = c0 + 2 >= nch;
-      const long dA = cur.base + (long)(c0 + 1) * HB_BK;
-      const long dB = last ? nxt.base : cur.base + (long)(c0 + 2) * HB_BK;
+      const __amdgpu_buffer_rsrc_t rsA = halo_rsrc(cur.base), rsB = halo_rsrc(last ? nxt.base : cur.base);
+      const int sA = (c0 + 1) * HB_BK * 2, sB = last ? 0 : (c0 + 2) * HB_BK * 2;
       const unsigned vB = last ? nvm : cur.vmask;
       lich_for_seq(std::make_integer_sequence<int, 2 * NTAP>{}, [&](auto uc) {
         constexpr int U = decltype(uc)::value;
-        tap_step(uc, c0 + U / NTAP, U < NTAP ? dA : dB, U < NTAP ? cur.vmask : vB);
+        if constexpr (U < NTAP) tap_step(uc, c0, rsA, sA, cur.vmask);
+        else tap_step(uc, c0 + 1, rsB, sB, vB);
       });
     }
     if (it == 0) HALO_STAMP(2);
@@ -395,7 +407,7 @@ __global__ __launch_bounds__(256, 1) void halo_conv_bf16_kernel(const IgemmHPara
     cur = nxt;
     tile = tnext;
   }
-  // in flight: the (unused) weight sets of the four taps past the end, A slot 0, zero-page pieces into buffer 0
+  // in flight: the (unused) weight sets of the four taps past the end, A slot 0, zero pieces into buffer 0
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
                : "+a"(af[0][0][0]), "+a"(af[0][0][1]), "+a"(af[0][1][0]), "+a"(af[0][1][1]), "+a"(af[0][2][0]),
                  "+a"(af[0][2][1]), "+a"(af[0][3][0]), "+a"(af[0][3][1]));

@@ -120,7 +120,7 @@ def test_halo_kernel_async_registers(tmp_path):
         tw = 2 if "ILi2" in name else 3
         assert mn.count("v_mfma_f32_32x32x16_bf16") == 50 * 8 * tw, (name, mn.count("v_mfma_f32_32x32x16_bf16"))
         assert mn.count("ds_read_b128") == 50 * 8 and mn.count("global_load_dwordx4") == 50 * 2 * tw
-        assert mn.count("global_load_lds_dwordx4") == 40 and mn.count("s_barrier") == 2
+        assert mn.count("buffer_load_dwordx4") == 40 and mn.count("s_barrier") == 2   # (the halo pieces: `... offen lds`)
         spill = [m for m in mn if m.startswith("scratch_") or m.startswith("v_accvgpr")]
         assert not spill, f"{name}: spill code inside the tap loop: {spill[:5]}"
         checked, bad = _audit_loads(body)
