@@ -235,11 +235,15 @@ def prepared(param: torch.Tensor, kind: str):
 
 
 def grad_like(param: torch.Tensor) -> torch.Tensor:
-    """Destination for `param`'s gradient: its slot in the all-reduce bucket when data parallelism registered one
-    and no gradient has been accumulated yet this step (autograd then adopts the slot as `.grad` without a
-    copy), else a fresh contiguous tensor."""
+    """Destination for `param`'s gradient: its slot in the all-reduce bucket when data parallelism registered one,
+    no gradient has been accumulated yet and the slot has not been handed out in this step (autograd then adopts
+    the slot as `.grad` without a copy), else a fresh contiguous tensor.  The slot goes out AT MOST ONCE per step
+    (entry[2], cleared by GradientAllReducer.reset()): a parameter used by two nodes of one graph -- a layer called
+    twice, shared weights -- would otherwise get the same destination for both weight-gradient launches, the second
+    overwriting the first, and autograd would add the two aliased handles (2x the last contribution, silently)."""
     e = GRAD_VIEWS.get(id(param)) if GRAD_VIEWS else None
-    if e is not None and e[0]() is param and param.grad is None:
+    if e is not None and e[0]() is param and param.grad is None and not e[2]:
+        e[2] = True
         return e[1].detach()   # a fresh handle on the slot: autograd adopts a gradient only if nobody else holds it
     return torch.empty_like(param, memory_format=torch.contiguous_format)
 

@@ -81,7 +81,7 @@ class GradientAllReducer:
                 for i, o in zip(idxs, offs):
                     p = self.params[i]
                     self._views[i] = flat[o:o + p.numel()].view(p.shape)
-                    F_.GRAD_VIEWS[id(p)] = (weakref.ref(p), self._views[i])
+                    F_.GRAD_VIEWS[id(p)] = [weakref.ref(p), self._views[i], False]   # [param, slot, handed out this step]
         self._pending = [0] * len(self.buckets)
         self._work = [None] * len(self.buckets)
         self._events = [[] for _ in self.buckets]  # one per gradient: backward may run on several streams
@@ -112,6 +112,10 @@ class GradientAllReducer:
         # ended (diagnostic: the weight-gradient kernels are expected to write theirs in place)
         self.copied_last_step = getattr(self, "_copied", [])
         self._copied = []
+        for p in self.params:   # functional.grad_like may hand every slot out again
+            e = F_.GRAD_VIEWS.get(id(p))
+            if e is not None and e[0]() is p:
+                e[2] = False
         for b, idxs in enumerate(self.buckets):
             self._pending[b] = len(idxs)
             self._work[b] = None

@@ -59,6 +59,25 @@ def main():
         for m in (model.encoder.net[0], model.encoder.net[2], model.decoder.net[0], model.decoder.net[6],
                   model.context_model.masked, model.entropy_parameters.net[0]):
             assert ids.index(id(m.weight)) not in red.copied_last_step, "a weight gradient was copied into its bucket"
+    # a weight used by TWO nodes of one graph: the bucket slot is handed to the first weight-gradient
+    # launch only, the second gets its own tensor and autograd adds them -- the sum, not twice the last one
+    red.remove()
+    from neural_image_compression_amd import layers as LY
+    torch.manual_seed(3)
+    conv = LY.Conv2d(16, 16, 3, stride=1, padding=1).to(dev)
+    broadcast_parameters(conv)
+    xs2 = torch.rand(2 * world, 16, 12, 12, generator=g).to(dev).contiguous(memory_format=torch.channels_last)
+    y2 = conv(conv(xs2))
+    (y2 * y2).mean().backward()                      # whole batch, no reducer
+    want = [q.grad.clone() for q in conv.parameters()]
+    conv.zero_grad(set_to_none=True)
+    red2 = GradientAllReducer(conv.parameters(), bucket_mb=1.0)
+    y2 = conv(conv(xs2[2 * rank:2 * rank + 2].contiguous(memory_format=torch.channels_last)))
+    (y2 * y2).mean().backward()
+    red2.finish()
+    for q, w_ in zip(conv.parameters(), want):
+        assert float((q.grad - w_).abs().max()) <= 3e-4 * float(w_.abs().max()) + 1e-7, "gradient of a weight used twice"
+    red2.remove()
     # every rank must hold the same averaged gradients
     flat = torch.cat([p.grad.reshape(-1) for p in model.parameters()]).cpu()
     got = [torch.empty_like(flat) for _ in range(world)]

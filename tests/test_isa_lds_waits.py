@@ -132,3 +132,84 @@ def test_the_checker_itself_flags_uncovered_reads():
     assert len(_check_kernel("k", moved)[1]) == 1                                # a fragment register copied before the wait
     behind_branch = [("ds_read_b128", "v[2:5], v66"), ("s_cbranch_scc1", "65000"), ("v_mov_b32_e32", "v20, v3")]
     assert _check_kernel("k", behind_branch) == (0, [])
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# The hand-over rule of the 8-wave ping-pong tiles (igemm_bf16_kernel<256, TN, ..., 4, 8>): the two wave
+# groups read LDS rows and weight-panel pieces that OTHER waves DMA'd, so a chunk may be read only one phase after
+# the wait that retires it: every `s_barrier` behind which fragments are read must be preceded -- after the last
+# LDS-DMA issue in front of it -- by an `s_waitcnt vmcnt(N)` with N <= (RING - 2) * NL (NL = DMA instructions per
+# thread per chunk; RING = 4), i.e. every wave has waited for ITS pieces of the chunk before anybody passes the
+# barrier.  The racy version of round 2 (e6ea9d4) waited AFTER that barrier, which orders only a wave's own pieces;
+# it passed every parity test and produced NaNs in the two-stream training step.  This checker flags it (verified
+# on that commit's kernel, tools/check_handover_on_commit.sh) and passes on the kernels in the tree.
+# ---------------------------------------------------------------------------------------------------------------
+_VMC = re.compile(r"vmcnt\((\d+)\)")
+
+
+def _check_handover(name, insns, bound):
+    """every fragment-read group (ds_read_b128 right behind an s_barrier) must have, between the last DMA issue in
+    front of that barrier and the barrier, a wait vmcnt(<= bound).  Returns (groups checked, violations)."""
+    bad, checked = [], 0
+    for i, (mn, ops) in enumerate(insns):
+        if mn != "ds_read_b128" or i == 0:
+            continue
+        # first read of a group: walk back over non-LDS instructions to the barrier it sits behind
+        # (in textual order, through the branches of conditional waits: the racy version had some here)
+        j = i - 1
+        while j >= 0 and insns[j][0] not in ("s_barrier", "ds_read_b128", "global_load_lds_dwordx4") and \
+                not insns[j][0].startswith("v_mfma"):
+            j -= 1
+        if j < 0 or insns[j][0] != "s_barrier":
+            continue
+        checked += 1
+        k, ok, seen_dma = j - 1, False, False
+        while k >= 0:
+            m2, o2 = insns[k]
+            if m2 == "global_load_lds_dwordx4":
+                seen_dma = True
+                break
+            if m2 in ("s_endpgm", "s_setpc_b64"):
+                break
+            if m2 == "s_waitcnt":
+                mm = _VMC.search(o2)
+                if mm is not None and int(mm.group(1)) <= bound:
+                    ok = True
+            k -= 1
+        if seen_dma and not ok:
+            bad.append(f"{name}: fragment reads at #{i} follow a barrier with no vmcnt(<= {bound}) between the DMA issue "
+                       f"at #{k} and the barrier at #{j}")
+    return checked, bad
+
+
+def _nl_bound(name):
+    """(RING - 2) * NL of igemm_bf16_kernel<256, TN, ., ., 4, 8>: APASS = 2, BPASS = ceil(256 TN / 512)"""
+    m = re.search(r"igemm_bf16_kernelILi256ELi(\d)E", name)
+    tn = int(m.group(1))
+    return 2 * (2 + (256 * tn + 511) // 512)
+
+
+@pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="needs ROCm's llvm-objdump")
+def test_eight_wave_tiles_wait_for_their_dma_before_the_barrier_that_publishes_it(tmp_path):
+    kernels = _disassemble(tmp_path)
+    eight = {k: v for k, v in kernels.items() if "igemm_bf16_kernelILi256E" in k and k.endswith("Li8EEv12IgemmHParams")}
+    assert len(eight) >= 6, sorted(eight)
+    total = 0
+    for name, insns in eight.items():
+        n, bad = _check_handover(name, insns, _nl_bound(name))
+        assert not bad, "\n".join(bad[:5])
+        total += n
+    assert total >= 3 * len(eight), total   # the unrolled ring: several read groups per kernel
+
+
+def test_the_handover_checker_flags_a_wait_behind_the_barrier():
+    dma = ("global_load_lds_dwordx4", "v[0:1], off")
+    good = [dma, ("s_waitcnt", "vmcnt(8) lgkmcnt(0)"), ("s_barrier", ""), ("v_mfma_f32_32x32x16_bf16", "a[0:15], v[0:3], v[4:7], a[0:15]"),
+            ("s_barrier", ""), ("ds_read_b128", "v[0:3], v9"), ("ds_read_b128", "v[4:7], v9 offset:16")]
+    assert _check_handover("k", good, 8) == (1, [])
+    # the racy shape: the wait sits BEHIND the barrier (it orders only the wave's own pieces)
+    racy = [dma, ("s_waitcnt", "lgkmcnt(0)"), ("s_barrier", ""), ("v_mfma_f32_32x32x16_bf16", "a[0:15], v[0:3], v[4:7], a[0:15]"),
+            ("s_barrier", ""), ("s_cbranch_vccz", "12"), ("s_waitcnt", "vmcnt(8)"), ("ds_read_b128", "v[0:3], v9")]
+    assert len(_check_handover("k", racy, 8)[1]) == 1
+    shallow = [dma, ("s_waitcnt", "vmcnt(12)"), ("s_barrier", ""), ("ds_read_b128", "v[0:3], v9")]
+    assert len(_check_handover("k", shallow, 8)[1]) == 1      # waits, but leaves too many pieces in flight
