@@ -107,7 +107,7 @@ typedef struct lic_igemm_desc {
    * tile needs >= 512 workgroups), so parity tests use these to put every kernel variant the full-size
    * workloads dispatch in front of the oracle at sizes the oracle finishes in seconds, and the entropy
    * coder pins one variant so that encoder and decoder build bit-identical tables whatever their batch.
-   *   force_bm in {64,128}, force_tn in {1,2,3} (both or neither; needs float4-aligned operands and
+   *   lic_igemm (fp32): force_bm in {64,128}, force_tn in {1,2,3} (both or neither; needs float4-aligned operands and
    *   Npad % (64*force_tn) == 0, else LIC_ERR_UNSUPPORTED); force_split >= 1: K splits
    *   (1 = never split; needs `workspace`). */
   int32_t force_bm, force_tn, force_split, reserved0;
@@ -266,8 +266,13 @@ int lic_pack_weight_bf16(const float* src, void* dst, int32_t taps, int32_t K, i
                          int64_t s_k, int64_t s_n, lic_stream_t stream);
 int lic_igemm_bf16(const lic_igemm_desc* d, int32_t out_f32, lic_stream_t stream);
 /* workspace size that lets lic_igemm_bf16 split K across workgroups for `d` (0 = large enough not to need it);
- * pass the buffer in d->workspace / workspace_bytes.  The split is a function of per-image geometry only.
- * force_split of the descriptor is honoured (1 = never, n > 1 = n splits). */
+ * pass the buffer in d->workspace / workspace_bytes.  The split and the choice between the tap-major tiles and the
+ * chunk-major halo-resident variant (the two things that change the summation order of an output) are functions of
+ * per-image geometry only: an image's bits do not depend on the batch it is computed in.  force_split of the
+ * descriptor is honoured (1 = never, n > 1 = n splits); force_bm in {64, 128, 256, 512}: 256 = the 8-wave
+ * ping-pong tile, 512 = the halo-resident 5x5 stride-2 kernel wherever a launch is eligible for it (other
+ * launches keep their automatic tile); force_tn is not used on this path (the N tile follows from the channel
+ * count; a value that contradicts it returns LIC_ERR_UNSUPPORTED). */
 size_t lic_igemm_bf16_workspace_bytes(const lic_igemm_desc* d);
 /* lic_igemm_bf16 also runs LIC_EPI_CONV_GDN / LIC_EPI_CONV_IGDN (the conv -> GDN pairs of Components.py:10-15,
  * 39-44 in one launch) when this returns 1 (Cout in {64,128,192}: one tile spans every output channel; bf16 `out`):

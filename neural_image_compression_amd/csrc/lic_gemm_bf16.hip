@@ -789,6 +789,15 @@ static int igemmh_prepare(const lic_igemm_desc* d, int32_t out_f32, IgemmHParams
     if (d->force_bm != 512) BM = d->force_bm;
   }
   if (fuse) BM = 128;  // (the fused pool's wave layout)
+  // K-split candidates (the tiny latent-side layers, see below) are decided from per-image geometry BEFORE the
+  // batch-dependent tile choice, so that the choice can never switch a split off: an image's bits do not depend
+  // on its batch (the 8-wave tile used to disable the split once the batch made it eligible)
+  int max_chunks = 0;
+  for (int ph = 0; ph < p.nphase; ++ph) max_chunks = p.ntaps[ph] * p.cpt > max_chunks ? p.ntaps[ph] * p.cpt : max_chunks;
+  const bool simple = (epi == LIC_EPI_NONE || epi == LIC_EPI_LEAKY) && !d->out2 && d->prologue == 0;
+  const long t_img = (((long)d->Ho * d->Wo + 63) / 64) * (p.Npad / 64);
+  const bool split_candidate = simple && d->workspace && d->force_split != 1 &&
+                               ((t_img < 4 && max_chunks >= 48) || d->force_split > 1) && max_chunks >= 2;
   // 256-row, 8-wave ping-pong variant (see the kernel): where it leaves at least one workgroup per CU
   {
     const char* e = getenv("LIC_BF16_PP");  // tuning aid: 0 = never
@@ -799,12 +808,15 @@ static int igemmh_prepare(const lic_igemm_desc* d, int32_t out_f32, IgemmHParams
     // stuck at one wave per SIMD there) -- but NOT 128-channel ones: config 3 7400 -> 7180 img/s, and the
     // fused 8x1 layout 135 -> 153 us (80 KB of fragment reads per chunk).
     const bool pays = TN == 3;
-    if (p.prologue != 1 && ((d->force_bm == 256) || (!d->force_bm && !off && pays && wgs256 >= 256))) BM = 256;
+    if (p.prologue != 1 && ((d->force_bm == 256) || (!d->force_bm && !off && pays && wgs256 >= 256 && !split_candidate)))
+      BM = 256;
     else if (d->force_bm == 256) BM = 128;  // (the squaring prologue has no 8-wave variant)
   }
   // Halo-resident variant (lic_halo_bf16.h; BM = 512 names it): the 5x5 stride-2 layers of the analysis / synthesis
   // stacks (Components.py:12,14,41,43 -- forward convolutions and the data gradients of the transposed ones) with
-  // 128 output channels, when the launch has at least half a workgroup per CU.  force_bm = 512 forces it on every
+  // 128 output channels and at least four 8 x 32 output tiles per IMAGE -- a rule of per-image geometry only: this
+  // variant sums K chunk-major, the others tap-major, and an image's bits must not depend on the batch it is
+  // computed in (tests/test_gpu_fullsize.py).  force_bm = 512 forces it on every
   // launch it covers (parity tests on small shapes; other launches keep their automatic tile), any other force_bm
   // and LIC_BF16_HALO=0 keep the implicit-GEMM tiles.
   p.htx = p.hty = 0;
@@ -817,7 +829,7 @@ static int igemmh_prepare(const lic_igemm_desc* d, int32_t out_f32, IgemmHParams
     const int htx = (d->Wo + halo::TWD - 1) / halo::TWD, hty = (d->Ho + halo::TH - 1) / halo::TH;
     const char* e = getenv("LIC_BF16_HALO");  // tuning aid: 0 = never
     const bool off = e && e[0] == '0';
-    if (shape_ok && (d->force_bm == 512 || (!d->force_bm && !off && (long)d->B * htx * hty >= 128))) {
+    if (shape_ok && (d->force_bm == 512 || (!d->force_bm && !off && htx * hty >= 4))) {
       BM = 512;
       p.htx = htx;
       p.hty = hty;
@@ -860,13 +872,8 @@ static int igemmh_prepare(const lic_igemm_desc* d, int32_t out_f32, IgemmHParams
   p.cps = 0;
   p.slabs = nullptr;
   {
-    int max_chunks = 0;
-    for (int ph = 0; ph < p.nphase; ++ph) max_chunks = p.ntaps[ph] * p.cpt > max_chunks ? p.ntaps[ph] * p.cpt : max_chunks;
-    const bool simple = (epi == LIC_EPI_NONE || epi == LIC_EPI_LEAKY) && !d->out2 && d->prologue == 0;
-    const long t_img = (((long)d->Ho * d->Wo + 63) / 64) * (p.Npad / 64);
     long S = 1;
-    if (simple && BM != 256 && d->workspace && d->force_split != 1 &&
-        ((t_img < 4 && max_chunks >= 48) || d->force_split > 1) && max_chunks >= 2) {
+    if (split_candidate && BM != 256) {
       S = (24 + t_img - 1) / t_img;
       if (S > max_chunks / 8) S = max_chunks / 8;  // at least 8 chunks (256 K) per split
       if (S > 32) S = 32;

@@ -131,6 +131,14 @@ class _HyperpriorContextModel(nn.Module):
     # restores the per-layer packing launches for an A/B
     use_step_prep = os.environ.get("LIC_STEP_PREP", "1") != "0"
 
+    def __getstate__(self):
+        # the step preparation holds weak references and device job tables of THIS object: a pickled / deep-copied
+        # model builds its own on first use
+        st = dict(self.__dict__)
+        st.pop("_step_prep", None)
+        st.pop("_side_stream", None)
+        return st
+
     def step_prep(self):
         if getattr(self, "_step_prep", None) is None:
             from .prep import StepPrep

@@ -20,6 +20,8 @@ from . import functional as F_
 
 
 class FusedAdam(torch.optim.Adam):
+    MAX_TENSORS = 448   # per parameter group (include/lic.h: lic_adam_run)
+
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, **kw):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, **kw)
         self._tables = {}   # group index -> (key, device job table, njobs, blocks, ctypes array of gradient pointers)
@@ -28,8 +30,8 @@ class FusedAdam(torch.optim.Adam):
     def _eligible(self, group, params, grads):
         if group["amsgrad"] or group.get("maximize") or group.get("capturable") or group.get("differentiable"):
             return False
-        if isinstance(group["lr"], torch.Tensor) or not params:
-            return False
+        if isinstance(group["lr"], torch.Tensor) or not params or len(params) > self.MAX_TENSORS:
+            return False   # (lic_adam_run's kernel-argument block holds MAX_TENSORS gradient addresses)
         dev = params[0].device
         for p, g in zip(params, grads):
             if p.device != dev or not p.is_cuda or p.dtype != torch.float32 or g.dtype != torch.float32 or \
@@ -68,13 +70,13 @@ class FusedAdam(torch.optim.Adam):
             _, dev_tab, njobs, blocks, gptrs = tab
             for i, g in enumerate(grads):       # gradients are fresh tensors every step: their addresses go along
                 gptrs[i] = g.data_ptr()         # as kernel arguments (copied at launch)
-            for s in steps:
-                s += 1
-            t = float(steps[0])
+            t = float(steps[0]) + 1.0
             beta1, beta2 = group["betas"]
             L.check(lib.lic_adam_run(C.c_void_p(dev_tab.data_ptr()), njobs, blocks, gptrs, float(group["lr"]), float(beta1),
                                      float(beta2), float(group["eps"]), float(group["weight_decay"]),
                                      1.0 - beta1 ** t, 1.0 - beta2 ** t, F_._stream()), "lic_adam_run")
+            for s in steps:     # (only once the launch went out: a refused launch leaves the state untouched)
+                s += 1
             # the kernel wrote through raw pointers: tell autograd (and prep.StepPrep, which re-derives the packed
             # weights when a parameter's version moves) that the parameters and moments changed
             torch.autograd.graph.increment_version(params + exp_avgs + exp_avg_sqs)

@@ -194,6 +194,9 @@ def broadcast_parameters(module: torch.nn.Module, src: int = 0, process_group=No
     with torch.no_grad():
         for t in list(module.parameters()) + list(module.buffers()):
             dist.broadcast(t, src=src, group=process_group)
+    sp = getattr(module, "_step_prep", None)   # packed weights derived before the broadcast are stale now
+    if sp is not None:
+        sp.invalidate()
 
 
 def shard_batch(n_items: int, rank: int, world: int):

@@ -147,6 +147,7 @@ class StepPrep:
         self._njobs, self._blocks = len(jobs), int(total)
         self._entries, self._params = entries, params
         self._versions = None
+        self._ptrs = None
 
     # ------------------------------------------------------------------------------------------
     def run(self):
@@ -158,6 +159,17 @@ class StepPrep:
             self._build()
         if self._jobs_dev is None:
             return
+        # a parameter whose STORAGE was replaced (p.data = ..., a re-allocation) leaves dangling pointers in the device
+        # job table: the table is rebuilt; a changed version counter only re-runs the launch
+        ptrs = [p.data_ptr() for p in self._params]
+        if ptrs != getattr(self, "_ptrs", None) and getattr(self, "_ptrs", None) is not None:
+            self._plist = None
+            self._sig = self._signature()
+            self._build()
+            if self._jobs_dev is None:
+                return
+            ptrs = [p.data_ptr() for p in self._params]
+        self._ptrs = ptrs
         versions = [p._version for p in self._params]
         if versions == self._versions:
             return
@@ -170,6 +182,13 @@ class StepPrep:
             if key not in F_.PREPARED:
                 self._keys.append(key)
             F_.PREPARED[key] = (p._version, t, weakref.ref(p))
+
+    def invalidate(self):
+        """Force the next run() to re-derive every buffer.  Needed after writes that do not bump a parameter's
+        version counter: `p.data.copy_()` / `p.data.mul_()` (EMA swaps, manual initialisation), raw-pointer kernels,
+        collectives on `.data`.  (optimizer steps, `load_state_dict` and in-place ops on the Parameter itself bump the
+        counter and need nothing.)"""
+        self._versions = None
 
     def release(self):
         _drop(self._keys)

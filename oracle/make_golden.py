@@ -230,6 +230,49 @@ def gen_rd_loss():
          dlogp_y=ty.grad.numpy(), dlogp_z=tz.grad.numpy(), dx_hat=th.grad.numpy(), **kw)
 
 
+def gen_vision_rd_loss():
+    """RateDistortionLoss.py:52-121 (the scalable model's loss; the function itself imports and runs although the
+    model it was written for does not): with and without the vision term.  V / frozen_activation are
+    arbitrary user modules: a 3x3 stride-2 convolution with recipe weights (stored in the fixture) and a Tanh."""
+    from RateDistortionLoss import vision_rd_loss
+    B = 3
+    r = np.random.RandomState(71)
+    logp_y1 = np.log(r.uniform(1e-9, 1.0, (B, 4, 4, 6))).astype(np.float32)
+    logp_y2 = np.log(r.uniform(1e-6, 1.0, (B, 4, 4, 6))).astype(np.float32)
+    logp_z = np.log(r.uniform(1e-3, 1.0, (B, 8, 1, 2))).astype(np.float32)
+    x = r.rand(B, 3, 16, 24).astype(np.float32)
+    xh = (x + 0.05 * r.randn(B, 3, 16, 24)).astype(np.float32)
+    ft = r.randn(B, 5, 8, 12).astype(np.float32)
+    vw = (r.randn(5, 3, 3, 3) / 5.0).astype(np.float32)
+    vb = (0.1 * r.randn(5)).astype(np.float32)
+    V = nn.Conv2d(3, 5, 3, stride=2, padding=1)
+    with torch.no_grad():
+        V.weight.copy_(T(vw))
+        V.bias.copy_(T(vb))
+    act = nn.Tanh()
+    kw = dict(logp_y1=logp_y1, logp_y2=logp_y2, logp_z=logp_z, x=x, x_hat=xh, F_tilde=ft, v_weight=vw, v_bias=vb,
+              lambda_rd=0.013, gamma=0.7)
+    for tag, mods in (("plain", (None, None)), ("vision", (act, V))):
+        t1, t2, tz, th, tf = T(logp_y1, True), T(logp_y2, True), T(logp_z, True), T(xh, True), T(ft, True)
+        for q in V.parameters():
+            q.grad = None
+        res = vision_rd_loss({"logp_y1": t1, "logp_y2": t2, "logp_z": tz, "x_hat": th, "F_tilde": tf}, T(x), 0.013, 0.7,
+                             frozen_activation=mods[0], V=mods[1])
+        res["loss"].backward()
+        for k, v in res.items():
+            if isinstance(v, float):
+                kw[f"{tag}.{k}"] = np.float64(v)
+            elif torch.is_tensor(v) and k != "loss":
+                kw[f"{tag}.{k}"] = v.numpy()
+        kw[f"{tag}.loss"] = np.float64(res["loss"].item())
+        kw[f"{tag}.dlogp_y1"], kw[f"{tag}.dlogp_y2"] = t1.grad.numpy(), t2.grad.numpy()
+        kw[f"{tag}.dlogp_z"], kw[f"{tag}.dx_hat"] = tz.grad.numpy(), th.grad.numpy()
+        if mods[1] is not None:
+            kw[f"{tag}.dF_tilde"] = tf.grad.numpy()
+            kw[f"{tag}.dv_weight"] = V.weight.grad.numpy().copy()
+    save("op_vision_rd_loss.npz", **kw)
+
+
 def gen_masked_conv():
     from ContextModels import ContextModel
     M, B, h, w = 4, 2, 6, 5
@@ -305,6 +348,7 @@ def main():
     gen_factorized()
     gen_gaussian()
     gen_rd_loss()
+    gen_vision_rd_loss()
     gen_masked_conv()
     _register_gdn_standin()
     gen_model("5x5", 8, 1, 2, 64, 64, seed=101)

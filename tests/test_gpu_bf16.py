@@ -310,6 +310,22 @@ def test_conv_bf16_split_is_batch_invariant(env):
         y6 = FB.conv2d_bf16(x, w, b, 2, 2)
         y2 = FB.conv2d_bf16(x[2:4].contiguous(memory_format=torch.channels_last), w, b, 2, 2)
     assert torch.equal(y6[2:4], y2)
+    # a 192-channel layer at a batch large enough for the 8-wave tile (>= 256 tiles of 256 rows): the tile
+    # choice must not switch the K split of this tiny-spatial layer off
+    xb = dev(rb(r.randn(4096, 192, 8, 8).astype(np.float32)), d, BF)
+    wb = dev(rb((r.randn(192, 192, 5, 5) / 69.0).astype(np.float32)), d).contiguous()
+    bb = dev(r.randn(192).astype(np.float32), d)
+    with torch.no_grad():
+        big = FB.conv2d_bf16(xb, wb, bb, 2, 2)
+        small = FB.conv2d_bf16(xb[5:7].contiguous(memory_format=torch.channels_last), wb, bb, 2, 2)
+    assert torch.equal(big[5:7], small)
+    # the halo-resident variant (chunk-major K order) is chosen from per-image geometry too: 64x64 inputs of the
+    # 128-channel layer take it at every batch
+    xh = dev(rb(r.randn(5, 128, 64, 64).astype(np.float32)), d, BF)
+    with torch.no_grad():
+        y5 = FB.conv2d_bf16(xh, w, b, 2, 2)
+        y1 = FB.conv2d_bf16(xh[3:4].contiguous(memory_format=torch.channels_last), w, b, 2, 2)
+    assert torch.equal(y5[3:4], y1)
 
 
 def _conv_bf16_ops(env, k, s, p, ci, co, H, W, B, tr, op):

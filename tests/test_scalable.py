@@ -85,3 +85,44 @@ def test_scalable_model_step_vs_torch_restatement(K, with_vision):
         if e > worst[1]:
             worst = (name, e)
     assert worst[1] <= 1e-3, worst
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["plain", "vision"])
+def test_vision_rd_loss_golden_gpu(tag):
+    """the HIP path (loss.vision_rd_loss -> lic_rd_loss_* with lambda / 255^2 folded in) against the fixture the
+    REFERENCE's vision_rd_loss produced (tests/golden/op_vision_rd_loss.npz, oracle/make_golden.py): every result
+    key and every gradient, with and without the vision term"""
+    import os
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    d = torch.device("cuda:0")
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "op_vision_rd_loss.npz"))
+    act = V = None
+    if tag == "vision":
+        V = torch.nn.Conv2d(3, 5, 3, stride=2, padding=1)
+        with torch.no_grad():
+            V.weight.copy_(torch.from_numpy(fx["v_weight"]))
+            V.bias.copy_(torch.from_numpy(fx["v_bias"]))
+        V, act = V.to(d), torch.nn.Tanh()
+    ts = {k: torch.from_numpy(fx[k]).to(d).requires_grad_(True) for k in ("logp_y1", "logp_y2", "logp_z", "x_hat", "F_tilde")}
+    res = nic.vision_rd_loss(ts, torch.from_numpy(fx["x"]).to(d), float(fx["lambda_rd"]), float(fx["gamma"]),
+                             frozen_activation=act, V=V)
+    res["loss"].backward()
+
+    def close(a, b, what, rel=1e-4):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        assert np.abs(a - b).max() <= rel * max(np.abs(b).max(), 1e-30) + 1e-9, (what, np.abs(a - b).max(), np.abs(b).max())
+
+    close(float(res["loss"]), float(fx[f"{tag}.loss"]), "loss")
+    for k in ("bpp_y1", "bpp_y2", "bpp_y", "bpp_z", "bpp_total", "mse", "reconstruction_mse", "psnr", "vision_mse", "bits_y1",
+              "bits_y2", "bits_y", "bits_z", "bits_total"):
+        close(res[k], float(fx[f"{tag}.{k}"]), k)
+    for k in ("mse_per_image", "reconstruction_mse_per_image", "psnr_per_image"):
+        close(res[k].cpu().numpy(), fx[f"{tag}.{k}"], k)
+    for k in ("logp_y1", "logp_y2", "logp_z", "x_hat"):
+        close(ts[k].grad.cpu().numpy(), fx[f"{tag}.d{k}"], "d" + k)
+    if tag == "vision":
+        close(res["vision_mse_per_image"].cpu().numpy(), fx["vision.vision_mse_per_image"], "vision_mse_per_image")
+        close(ts["F_tilde"].grad.cpu().numpy(), fx["vision.dF_tilde"], "dF_tilde")
+        close(V.weight.grad.cpu().numpy(), fx["vision.dv_weight"], "dV.weight")
