@@ -823,7 +823,7 @@ static int igemmh_prepare(const lic_igemm_desc* d, int32_t out_f32, IgemmHParams
   {
     const bool shape_ok = !p.transposed && d->kh == 5 && d->kw == 5 && d->stride == 2 && d->pad == 2 &&
                           (d->tap_mask == 0 || (d->tap_mask & 0x1FFFFFFu) == 0x1FFFFFFu) && d->prologue == 0 &&
-                          (epi == LIC_EPI_NONE || epi == LIC_EPI_LEAKY) && !d->out2 && d->Cin % 64 == 0 &&
+                          (((epi == LIC_EPI_NONE || epi == LIC_EPI_LEAKY) && !d->out2) || (fuse && !out_f32)) && d->Cin % 64 == 0 &&
                           d->Cout == 128 && d->Ho == (d->Hi - 1) / 2 + 1 &&
                           d->Wo == (d->Wi - 1) / 2 + 1 && (long)d->B * d->Hi * d->Wi * d->in_ld < 0x7FFFFFFFL;
     const int htx = (d->Wo + halo::TWD - 1) / halo::TWD, hty = (d->Ho + halo::TH - 1) / halo::TH;
@@ -926,7 +926,8 @@ LIC_EXPORT int lic_igemm_bf16_kernel_name(const lic_igemm_desc* d, char* buf, si
   if (rc < 0) return rc;
   if (!buf || n == 0) return LIC_ERR_INVALID;
   if (BM == 512) {
-    snprintf(buf, n, "halo_conv_bf16_kernel<%d>", p.Npad / 64);
+    snprintf(buf, n, "halo_conv_bf16_kernel<%d, %s, 0>", p.Npad / 64,
+             (p.epilogue == LIC_EPI_CONV_GDN || p.epilogue == LIC_EPI_CONV_IGDN) ? "true" : "false");
     return LIC_OK;
   }
   const bool fuse = p.epilogue == LIC_EPI_CONV_GDN || p.epilogue == LIC_EPI_CONV_IGDN;
@@ -958,17 +959,18 @@ LIC_EXPORT int lic_igemm_bf16(const lic_igemm_desc* d, int32_t out_f32, lic_stre
 #ifdef LIC_HALO_ABLATE
     if (const char* e = getenv("LIC_HALO_ABL")) {
       const int a = atoi(e);
-      if (a == 1) hipLaunchKernelGGL((halo_conv_bf16_kernel<2, 1>), grid, block, 0, s, p);
-      if (a == 2) hipLaunchKernelGGL((halo_conv_bf16_kernel<2, 2>), grid, block, 0, s, p);
-      if (a == 4) hipLaunchKernelGGL((halo_conv_bf16_kernel<2, 4>), grid, block, 0, s, p);
-      if (a == 3) hipLaunchKernelGGL((halo_conv_bf16_kernel<2, 3>), grid, block, 0, s, p);
-      if (a == 7) hipLaunchKernelGGL((halo_conv_bf16_kernel<2, 7>), grid, block, 0, s, p);
+      if (a == 1) hipLaunchKernelGGL((halo_conv_bf16_kernel<2, false, 1>), grid, block, 0, s, p);
+      if (a == 2) hipLaunchKernelGGL((halo_conv_bf16_kernel<2, false, 2>), grid, block, 0, s, p);
+      if (a == 4) hipLaunchKernelGGL((halo_conv_bf16_kernel<2, false, 4>), grid, block, 0, s, p);
+      if (a == 3) hipLaunchKernelGGL((halo_conv_bf16_kernel<2, false, 3>), grid, block, 0, s, p);
+      if (a == 7) hipLaunchKernelGGL((halo_conv_bf16_kernel<2, false, 7>), grid, block, 0, s, p);
       if (a) return lic_check_launch();
     }
 #endif
     // (a 192-channel instance, 128 x 96 per wave, compiles but needs more than the 256 + 256 registers: hipcc moves
     // fragments that are still in flight; not dispatched)
-    hipLaunchKernelGGL((halo_conv_bf16_kernel<2>), grid, block, 0, s, p);
+    if (fuse) hipLaunchKernelGGL((halo_conv_bf16_kernel<2, true>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((halo_conv_bf16_kernel<2>), grid, block, 0, s, p);
     return lic_check_launch();
   }
   if (BM == 256) {  // 8-wave ping-pong variant

@@ -73,7 +73,7 @@ __device__ unsigned long long g_halo_dbg[1024 * 10];
 #define HALO_STAMP(i)
 #endif
 
-template <int TW, int ABL = 0>
+template <int TW, bool FUSE = false, int ABL = 0>
 __global__ __launch_bounds__(256, 1) void halo_conv_bf16_kernel(const IgemmHParams p) {
   using namespace halo;
   constexpr int NB = 2 * TW;                      // weight fragment loads per tap per lane
@@ -337,6 +337,132 @@ __global__ __launch_bounds__(256, 1) void halo_conv_bf16_kernel(const IgemmHPara
     }
     if (it == 0) HALO_STAMP(2);
 
+    if constexpr (FUSE) {
+      // ---- conv -> GDN / IGDN in the same launch (LIC_EPI_CONV_GDN / CONV_IGDN; Components.py:12-15), as the fused
+      // variant of igemm_bf16_kernel does it: x = conv + bias rounded to bf16, x^2 rounded again is the B operand of
+      // norm^T = gamma_eff . (x^2)^T in the K order a lane owns its channels in (gamma_eff^T packed by
+      // lic_pack_weight_bf16_kperm), y = x * norm^-1/2 (or ^1/2) element-wise in the accumulator layout.  Here a wave
+      // holds only HALF the channels of its pixels (2 x 2 waves), so the x^2 fragments are exchanged through LDS:
+      // every wave writes its 16 fragments (4 row tiles x 2 channel tiles x 2 k steps, lane-linear 1 KiB each) into
+      // the halo buffer that is idle now (buffer 1: buffer 0 already holds the next tile's first chunk), one barrier,
+      // and reads back all 32 fragments of its pixel half -- its partner's lanes own the same pixels, so the exchange
+      // is a lane-wise copy.  A second barrier at the end keeps the next tile's DMA out of the buffer until every
+      // wave has read.
+      int lho = lh, lio = li, wno = wn, wmo = wm;
+      asm volatile("" : "+v"(lho), "+v"(lio), "+s"(wno), "+s"(wmo));
+      const bool inv = p.epilogue == LIC_EPI_CONV_IGDN;
+      unsigned char* xch = smem + BUFB;                       // [wm][a][channel tile 0..2TW-1][k step][64 lanes][16 B]
+      auto frag_at = [&](int wmi, int a, int tt, int s2) { return xch + ((((wmi * 4 + a) * (2 * TW) + tt) * 2 + s2) * 64 + lane) * 16; };
+      auto pack2 = [](f32x2 v) { return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)); };
+      auto store_tile = [&](bf16_t* base, long ld, long opix, bool rok, int cb, const unsigned (&pk)[8]) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+          const u32x2 r0 = __builtin_amdgcn_permlane32_swap(pk[4 * s2], pk[4 * s2 + 2], false, false);
+          const u32x2 r1 = __builtin_amdgcn_permlane32_swap(pk[4 * s2 + 1], pk[4 * s2 + 3], false, false);
+          if (rok) {
+            const hu32x4 o = {r0[0], r1[0], r0[1], r1[1]};
+            *reinterpret_cast<hu32x4*>(base + opix * ld + cb + 16 * s2 + 8 * lho) = o;
+          }
+        }
+      };
+      f32x4 bs[TW][4];
+#pragma unroll
+      for (int t = 0; t < TW; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) bs[t][g] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+      if (p.bias) {
+#pragma unroll
+        for (int t = 0; t < TW; ++t)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            bs[t][g] = *reinterpret_cast<const f32x4*>(p.bias + (wno * TW + t) * 32 + 4 * lho + 8 * g);
+      }
+      // 1. x -> bf16 (kept in the accumulators as the rounded value), x^2 -> bf16 -> LDS; the conv output if asked for
+#pragma unroll
+      for (int a = 0; a < 4; ++a) {
+        const int oy = cur.oy0 + 4 * wmo + a, ox = cur.ox0 + lio;
+        const bool rok = oy < p.Ho && ox < p.Wo;
+        const long opix = rok ? ((long)cur.b * p.Ho + oy) * p.Wo + ox : 0;
+#pragma unroll
+        for (int t = 0; t < TW; ++t) {
+          unsigned xpk[8], sqpk[8];
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const f32x2 v = {acc[a][t][4 * g + 2 * h] + bs[t][g][2 * h], acc[a][t][4 * g + 2 * h + 1] + bs[t][g][2 * h + 1]};
+              const unsigned pk = pack2(v);
+              xpk[2 * g + h] = pk;
+              const f32x2 xb = {__builtin_bit_cast(float, pk << 16), __builtin_bit_cast(float, pk & 0xffff0000u)};
+              acc[a][t][4 * g + 2 * h] = xb[0];
+              acc[a][t][4 * g + 2 * h + 1] = xb[1];
+              sqpk[2 * g + h] = pack2(xb * xb);
+            }
+          if (p.out3) store_tile(p.out3, p.out3_ld, opix, rok, (wno * TW + t) * 32, xpk);
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2)
+            *reinterpret_cast<hu32x4*>(frag_at(wmo, a, wno * TW + t, s2)) =
+                hu32x4{sqpk[4 * s2], sqpk[4 * s2 + 1], sqpk[4 * s2 + 2], sqpk[4 * s2 + 3]};
+        }
+      }
+      __syncthreads();
+      // 2. + 3. two row tiles at a time (register budget): pool over all 2 TW input channel tiles, then finish
+      const bf16_t* gA = p.aux + lane * 8;
+      const int ntile = p.Npad >> 5;
+#pragma unroll
+      for (int hh = 0; hh < 2; ++hh) {
+        f32x16 nacc[2][TW];
+#pragma unroll
+        for (int a2 = 0; a2 < 2; ++a2)
+#pragma unroll
+          for (int t = 0; t < TW; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) nacc[a2][t][r] = 0.0f;
+#pragma unroll
+        for (int tt = 0; tt < 2 * TW; ++tt)
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+            bf16x8 b2[2];
+#pragma unroll
+            for (int a2 = 0; a2 < 2; ++a2) b2[a2] = *reinterpret_cast<const bf16x8*>(frag_at(wmo, 2 * hh + a2, tt, s2));
+#pragma unroll
+            for (int t = 0; t < TW; ++t) {
+              const bf16x8 a2f = *reinterpret_cast<const bf16x8*>(gA + ((long)tt * ntile + (wno * TW + t)) * 1024 + s2 * 512);
+#pragma unroll
+              for (int a2 = 0; a2 < 2; ++a2)
+                nacc[a2][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2f, b2[a2], nacc[a2][t], 0, 0, 0);
+            }
+          }
+#pragma unroll
+        for (int a2 = 0; a2 < 2; ++a2) {
+          const int a = 2 * hh + a2;
+          const int oy = cur.oy0 + 4 * wmo + a, ox = cur.ox0 + lio;
+          const bool rok = oy < p.Ho && ox < p.Wo;
+          const long opix = rok ? ((long)cur.b * p.Ho + oy) * p.Wo + ox : 0;
+#pragma unroll
+          for (int t = 0; t < TW; ++t) {
+            const int cb = (wno * TW + t) * 32;
+            unsigned npk[8], ypk[8];
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + cb + 4 * lho + 8 * g);
+#pragma unroll
+              for (int h = 0; h < 2; ++h) {
+                const f32x2 nv = {nacc[a2][t][4 * g + 2 * h] + be[2 * h], nacc[a2][t][4 * g + 2 * h + 1] + be[2 * h + 1]};
+                npk[2 * g + h] = pack2(nv);
+                const f32x2 f = {inv ? __builtin_amdgcn_sqrtf(nv[0]) : __builtin_amdgcn_rsqf(nv[0]),
+                                 inv ? __builtin_amdgcn_sqrtf(nv[1]) : __builtin_amdgcn_rsqf(nv[1])};
+                const f32x2 xv = {acc[a][t][4 * g + 2 * h], acc[a][t][4 * g + 2 * h + 1]};
+                ypk[2 * g + h] = pack2(xv * f);
+              }
+            }
+            if (p.out2) store_tile(p.out2, p.out2_ld, opix, rok, cb, npk);
+            store_tile(reinterpret_cast<bf16_t*>(p.out), p.out_ld, opix, rok, cb, ypk);
+          }
+        }
+      }
+      __syncthreads();   // (the next tile's second chunk is DMA'd into the exchange buffer)
+    } else
     // ---- epilogue, straight from the registers: lane (li, lh) holds, of tile (a, t), pixel li of output row
     // 4 wm + a and channels 32 (wn TW + t) + 8 g + 4 lh + {0..3}, g = 0..3.  LeakyReLU as max(v, slope v) (slope 1 =
     // none); the bias is fetched in one batch (a load per tile would drain the stores in flight every time).

@@ -159,7 +159,7 @@ def test_halo_conv_forced_onto_small_ragged_shapes(env, ci, co, H, W, B):
         _conv_bf16_ops(env, 5, 2, 2, ci, co, H, W, B, False, 0)
     finally:
         F_.FORCE_IGEMM, F_.KERNEL_TRACE = None, None
-    assert "halo_conv_bf16_kernel<2>" in names, names
+    assert "halo_conv_bf16_kernel<2, false, 0>" in names, names
 
 
 def test_halo_conv_at_full_size_beside_a_second_stream(env):
@@ -204,7 +204,7 @@ def test_halo_conv_at_full_size_beside_a_second_stream(env):
                         assert torch.equal(o, f0), f"iteration {it}: the halo kernel is not bit-repeatable"
         finally:
             F_.FORCE_IGEMM, F_.KERNEL_TRACE = None, None
-    assert names == {"halo_conv_bf16_kernel<2>"}, names
+    assert names == {"halo_conv_bf16_kernel<2, false, 0>"}, names
 
 
 def test_dispatched_eight_wave_tiles_at_full_size_beside_a_second_stream(env):
@@ -436,6 +436,9 @@ def test_gdn_bf16(env, inverse):
     (5, 2, 2, 64, 128, 40, 36, 2, False, 0, False, 256),  # the 8-wave ping-pong tile with the fused pool
     (5, 2, 2, 128, 192, 18, 22, 1, False, 0, False, 256),
     (5, 2, 2, 64, 64, 13, 11, 2, True, 1, True, 256),     # ... transposed, 4 phases, IGDN
+    (5, 2, 2, 64, 128, 37, 45, 2, False, 0, False, 512),  # the halo-resident kernel with the fused pool: partial tiles
+    (5, 2, 2, 128, 128, 64, 64, 3, False, 0, False, 512), # ... four full tiles per image, two per workgroup and more
+    (5, 2, 2, 192, 128, 16, 20, 2, False, 0, True, 512),  # ... six chunks, IGDN
 ])
 def test_conv_gdn_fused_bf16_matches_two_launches(env, k, s, p, ci, co, H, W, B, tr, op, inverse, bm):
     nic, FB, O, d = env
@@ -487,6 +490,8 @@ def test_conv_gdn_fused_bf16_matches_two_launches(env, k, s, p, ci, co, H, W, B,
     tn = co // 64
     if stem and (k, s, p) == (5, 2, 2):
         assert f"stem_gdn_bf16_kernel<{co // 32}, {8 if co == 192 else 4}>" in names, names
+    elif bm == 512:
+        assert "halo_conv_bf16_kernel<2, true, 0>" in names and "halo_conv_bf16_kernel<2, false, 0>" in names, names
     else:
         assert any(n.startswith(f"igemm_bf16_kernel<{256 if bm == 256 else 128}, {tn}, false, true") for n in names), names
     whats = ["y"] + ([] if stem else ["dx"]) + ["dw", "db", "dbeta", "dgamma"]

@@ -53,3 +53,44 @@ def test_fused_adam_matches_torch_adam(wd):
     oc = FusedAdam(mb.parameters(), lr=1e-3, amsgrad=True)
     oc.step()
     assert oc.fused_steps == 0
+
+
+def test_fused_adam_fast_path_follows_changes():
+    """the cached plan of FusedAdam.step() (host fast path) must notice what it depends on: a learning-rate change
+    (schedulers write group['lr']), a parameter without a gradient (torch skips it: the fused launch cannot), a loaded
+    state dict -- each compared with torch.optim.Adam doing the same"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+    from neural_image_compression_amd.optim import FusedAdam
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    pa = [torch.nn.Parameter(torch.randn(n, device=dev)) for n in (1000, 37, 4096)]
+    pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+    oa, ob = torch.optim.Adam(pa, lr=1e-2), FusedAdam(pb, lr=1e-2)
+
+    def both(skip=None):
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            g = torch.randn_like(a)
+            a.grad, b.grad = (None, None) if i == skip else (g, g.clone())
+        oa.step()
+        ob.step()
+        for a, b in zip(pa, pb):
+            assert float((a.detach() - b.detach()).abs().max()) <= 2e-6 * max(1.0, float(a.detach().abs().max()))
+
+    both()
+    both()                                   # planned, then the fast path
+    assert ob.fused_steps == 2 and ob._fast is not None
+    for o in (oa, ob):
+        o.param_groups[0]["lr"] = 3e-3       # what a scheduler does
+    both()
+    assert ob.fused_steps == 3
+    both(skip=1)                             # torch leaves parameter 1 alone; FusedAdam must not update it either
+    assert ob.fused_steps == 3               # (that call went through torch's implementation)
+    both()
+    assert ob.fused_steps == 3               # (step counts differ between parameters now: torch's path, by design)
+    import copy
+    ob.load_state_dict(copy.deepcopy(oa.state_dict()))   # new state tensors (a deep copy: load_state_dict keeps
+    #                                                      references): the cached plan is dropped
+    assert ob._fast is None
+    both()
+    both()
