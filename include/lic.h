@@ -237,6 +237,13 @@ int lic_factorized_fwd(const float* x, const float* fe_params, float* p, float* 
 int lic_factorized_bwd(const float* x, const float* fe_params, const float* dp, const float* dlogp,
                        float* dx, float* dfe_params, int64_t P, int32_t C, float bound,
                        lic_stream_t stream);
+/* The factorised model's 11 parameter tensors (EntropyModels.py:62-86, each contiguous [C][out][in]) gathered into
+ * the [C][43] operand above / its [C][43] gradient scattered into a parameter-major buffer (parameter k's [C][n_k]
+ * block at offset C * prefix_k: each block has the parameter's own layout, so its views are the parameters'
+ * gradients), one launch each.  params11_host: HOST array of the 11 device pointers in the order matrices, biases,
+ * factors. */
+int lic_fe_pack(const void* const* params11_host, float* packed, int32_t C, lic_stream_t stream);
+int lic_fe_unpack(const float* dpacked, float* flat, int32_t C, lic_stream_t stream);
 /* channel_logits_cumulative (EntropyModels.py:153-169): out[i] = L_ch(xs[i]) */
 int lic_factorized_channel_logits(const float* fe_params, int32_t ch, const float* xs, float* out,
                                   int64_t n, lic_stream_t stream);

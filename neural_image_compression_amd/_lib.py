@@ -90,6 +90,8 @@ SIGNATURES = {
     "lic_factorized_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     "lic_factorized_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     "lic_factorized_channel_logits": (C.c_int, [_vp, _i32, _vp, _vp, _i64, _vp]),
+    "lic_fe_pack": (C.c_int, [_vp, _vp, _i32, _vp]),
+    "lic_fe_unpack": (C.c_int, [_vp, _vp, _i32, _vp]),
     "lic_rd_loss_workspace_bytes": (_sz, [_i32]),
     "lic_rd_loss_fwd": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _vp, _i64, _i32, _i64, _f32, _vp, _vp, _sz, _vp]),
     "lic_rd_loss_bwd": (C.c_int, [_vp, _vp, _i64, _i64, _i64, _i32, _i64, _f32, _vp, _vp, _vp, _vp, _vp]),

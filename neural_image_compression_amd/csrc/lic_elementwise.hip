@@ -635,6 +635,49 @@ LIC_EXPORT int lic_factorized_bwd(const float* x, const float* fe_params, const 
                      dlogp, dx, dfe_params, (long)P, C, bound);
   return lic_check_launch();
 }
+// The 11 parameter tensors of the factorised model (EntropyModels.py:62-86: matrices [C,3,1] [C,3,3] [C,3,3] [C,1,3],
+// biases [C,3,1] x3 [C,1,1], factors [C,3,1] x3; each contiguous) <-> the [C][43] operand of the kernels above, in
+// ONE launch each way.  The host side used torch.cat for the forward and left autograd to copy the 11 strided column
+// slices of the [C][43] gradient one by one (12 launches per step for 5,504 floats).  `flat` is the parameter-major
+// gradient buffer: parameter k's [C][n_k] block at C * prefix_k, i.e. each block has its parameter's own layout.
+struct FePtrs {
+  const float* p[11];
+};
+__constant__ int c_fe_n[11] = {3, 9, 9, 3, 3, 3, 3, 1, 3, 3, 3};
+__constant__ int c_fe_pre[12] = {0, 3, 12, 21, 24, 27, 30, 33, 34, 37, 40, 43};
+__global__ __launch_bounds__(256) void fe_pack_kernel(FePtrs ptrs, float* packed, int C) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= C * 43) return;
+  const int c = i / 43, j = i - c * 43;
+  int k = 0;
+#pragma unroll
+  for (int q = 1; q < 11; ++q) k += (j >= c_fe_pre[q]) ? 1 : 0;
+  packed[i] = ptrs.p[k][c * c_fe_n[k] + (j - c_fe_pre[k])];
+}
+__global__ __launch_bounds__(256) void fe_unpack_kernel(const float* dpk, float* flat, int C) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= C * 43) return;
+  const int c = i / 43, j = i - c * 43;
+  int k = 0;
+#pragma unroll
+  for (int q = 1; q < 11; ++q) k += (j >= c_fe_pre[q]) ? 1 : 0;
+  flat[(long)C * c_fe_pre[k] + c * c_fe_n[k] + (j - c_fe_pre[k])] = dpk[i];
+}
+LIC_EXPORT int lic_fe_pack(const void* const* params11_host, float* packed, int32_t C, lic_stream_t stream) {
+  if (!params11_host || !packed || C <= 0) return LIC_ERR_INVALID;
+  FePtrs ptrs;
+  for (int k = 0; k < 11; ++k) {
+    if (!params11_host[k]) return LIC_ERR_INVALID;
+    ptrs.p[k] = (const float*)params11_host[k];
+  }
+  hipLaunchKernelGGL(fe_pack_kernel, dim3((C * 43 + 255) / 256), dim3(256), 0, (hipStream_t)stream, ptrs, packed, C);
+  return lic_check_launch();
+}
+LIC_EXPORT int lic_fe_unpack(const float* dpacked, float* flat, int32_t C, lic_stream_t stream) {
+  if (!dpacked || !flat || C <= 0) return LIC_ERR_INVALID;
+  hipLaunchKernelGGL(fe_unpack_kernel, dim3((C * 43 + 255) / 256), dim3(256), 0, (hipStream_t)stream, dpacked, flat, C);
+  return lic_check_launch();
+}
 LIC_EXPORT int lic_factorized_channel_logits(const float* fe_params, int32_t ch, const float* xs, float* out,
                                              int64_t n, lic_stream_t stream) {
   if (!fe_params || !xs || !out || n <= 0 || ch < 0) return LIC_ERR_INVALID;

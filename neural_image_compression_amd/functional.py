@@ -927,6 +927,7 @@ class _GmmLikelihoodFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, params, K, bound):
         _require_cuda(x, params)
+        ctx.set_materialize_grads(False)   # (p is not part of the loss: no zero-filled gradient for it)
         xh, ph = _nhwc(x), _nhwc(params)
         B, H, W, M = xh.shape
         p = torch.empty_like(xh)
@@ -962,14 +963,27 @@ def gmm_likelihood(x, params, K, bound=LIKELIHOOD_BOUND):
 _FE_SIZES = [3, 9, 9, 3, 3, 3, 3, 1, 3, 3, 3]
 
 
+def _fe_pack(plist, Cc):
+    """[C][43] operand of the factorised kernels from the 11 parameter tensors: one gather launch when they are the
+    reference's contiguous fp32 tensors, torch.cat otherwise"""
+    if len(plist) == 11 and all(q.is_contiguous() and q.dtype == torch.float32 and q.shape[0] == Cc for q in plist) and \
+            [q.shape[1] * q.shape[2] for q in plist] == _FE_SIZES:
+        packed = torch.empty((Cc, 43), device=plist[0].device, dtype=torch.float32)
+        ptrs = (C.c_void_p * 11)(*[q.data_ptr() for q in plist])
+        L.check(L.load().lic_fe_pack(ptrs, _ptr(packed), Cc, _stream()), "lic_fe_pack")
+        return packed
+    return torch.cat([q.reshape(Cc, -1) for q in plist], dim=1).contiguous()
+
+
 class _FactorizedFn(torch.autograd.Function):
     """EntropyModels.py:49-151 (+ clamp :29-31, log Models.py:83-84)."""
 
     @staticmethod
     def forward(ctx, x, bound, *plist):
         _require_cuda(x, *plist)
+        ctx.set_materialize_grads(False)   # (p is not part of the loss: no zero-filled gradient for it)
         Cc = plist[0].shape[0]
-        packed = torch.cat([q.reshape(Cc, -1) for q in plist], dim=1).contiguous()  # [C,43] (plumbing)
+        packed = _fe_pack(plist, Cc)
         if x.dim() == 4:
             xh = _nhwc(x)
         else:  # (B, C) or (B, C, N): bring channels last
@@ -1005,7 +1019,16 @@ class _FactorizedFn(torch.autograd.Function):
         L.check(L.load().lic_factorized_bwd(_ptr(xh), _ptr(packed), _ptr(gph), _ptr(glh), _ptr(dx), _ptr(dpk),
                                             P, Cc, bound, _stream()), "lic_factorized_bwd")
         dxo = _nchw_view(dx) if len(xshape) == 4 else dx.permute(0, 3, 1, 2).reshape(xshape)
-        grads = [g.reshape(s) for g, s in zip(torch.split(dpk, _FE_SIZES, dim=1), pshapes)]
+        if len(pshapes) == 11 and [s_[1] * s_[2] for s_ in pshapes] == _FE_SIZES:
+            # one launch: the [C][43] gradient scattered parameter-major; each block IS a parameter's gradient
+            flat = torch.empty((Cc * 43,), device=dpk.device, dtype=torch.float32)
+            L.check(L.load().lic_fe_unpack(_ptr(dpk), _ptr(flat), Cc, _stream()), "lic_fe_unpack")
+            grads, off = [], 0
+            for n_, s_ in zip(_FE_SIZES, pshapes):
+                grads.append(flat[off:off + Cc * n_].view(s_))
+                off += Cc * n_
+        else:
+            grads = [g.reshape(s) for g, s in zip(torch.split(dpk, _FE_SIZES, dim=1), pshapes)]
         return (dxo, None, *grads)
 
 

@@ -26,6 +26,7 @@ class FusedAdam(torch.optim.Adam):
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, **kw)
         self._tables = {}   # group index -> (key, device job table, njobs, blocks, ctypes array of gradient pointers)
         self._fast = None   # the last planned step, re-used while nothing it depends on changed
+        self._t0, self._lazy = 0.0, 0   # step count the plan started from / fast steps not yet written to the state
         self.fused_steps = 0
 
     def _eligible(self, group, params, grads):
@@ -72,16 +73,18 @@ class FusedAdam(torch.optim.Adam):
                     _, dev_tab, njobs, blocks, gptrs = tab
                     for i, p in enumerate(params):
                         gptrs[i] = p.grad.data_ptr()
-                    t = float(steps[0]) + 1.0
+                    t = self._t0 + self._lazy + 1.0
                     beta1, beta2 = group["betas"]
                     L.check(lib.lic_adam_run(C.c_void_p(dev_tab.data_ptr()), njobs, blocks, gptrs, float(group["lr"]),
                                              float(beta1), float(beta2), float(group["eps"]), float(group["weight_decay"]),
                                              1.0 - beta1 ** t, 1.0 - beta2 ** t, F_._stream()), "lic_adam_run")
-                    for s in steps:
-                        s += 1
                     torch.autograd.graph.increment_version(moments)
+                # the per-parameter `step` tensors of the state (CPU scalars, one per parameter: bumping them is ~240
+                # small ATen calls per step) are brought up to date lazily: _flush_steps() before anything reads them
+                self._lazy += 1
                 self.fused_steps += 1
                 return loss
+        self._flush_steps()
         self._fast = None
         plans = []
         for gi, group in enumerate(self.param_groups):
@@ -125,21 +128,50 @@ class FusedAdam(torch.optim.Adam):
             # (the job table holds the parameter / moment addresses: valid while these very tensors are the state)
             if all(p.data_ptr() == k[0] for p, k in zip(params, tab[0])) and len(params) == len(group["params"]):
                 fast.append((group, group["params"], list(params), hyper, (tab, moments, list(steps))))
-        if len(fast) == len(self.param_groups):
+        if len(fast) == len(self.param_groups) and len({float(f[4][2][0]) for f in fast}) == 1:
             self._fast = fast
+            self._t0, self._lazy = float(fast[0][4][2][0]), 0
         self.fused_steps += 1
         return loss
 
+    def _flush_steps(self):
+        """apply the step counts the fast path has not yet written into the state's `step` tensors"""
+        n, fast = getattr(self, "_lazy", 0), self._fast
+        if n and fast is not None:
+            for _, _, _, _, (_, _, steps) in fast:
+                for s in steps:
+                    s += n
+            self._t0 += n
+        self._lazy = 0
+
+    def state_dict(self):
+        self._flush_steps()
+        return super().state_dict()
+
+    def zero_grad(self, set_to_none: bool = True):
+        # (torch's zero_grad walks every group through a profiler scope and foreach bookkeeping: 0.1 ms for 59 tensors)
+        if set_to_none and self._fast is not None:
+            for _, _, params, _, _ in self._fast:
+                for p in params:
+                    p.grad = None
+            return
+        return super().zero_grad(set_to_none)
+
     def load_state_dict(self, state_dict):
+        self._flush_steps()
         self._fast = None          # (new state tensors: plan again)
         self._tables = {}
         return super().load_state_dict(state_dict)
 
     def add_param_group(self, param_group):
+        if getattr(self, "_fast", None) is not None:
+            self._flush_steps()
         self._fast = None
         return super().add_param_group(param_group)
 
     def _fallback(self, loss):
         """torch's own update for this call (state was initialised by the same `_init_group`)"""
+        self._flush_steps()
+        self._fast = None
         super().step()
         return loss
