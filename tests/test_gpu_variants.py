@@ -18,6 +18,7 @@ fp32 tolerance: 1e-4 relative (north star); bf16-storage tolerances are declared
 Run on the MI355X box:  python -m pytest tests -m gpu -x -q
 """
 import math
+import os
 
 import numpy as np
 import pytest
@@ -411,22 +412,32 @@ def test_cfg5_one_image_train_step_vs_c_oracle(env):
         _compare_fp32(model, out, res, o_out, o_loss, o_grads, grad_tol=2e-3)
 
 
+# bands of the bf16-storage mode at full size: 2x the deviations measured on an MI355X (profiles/r03_bf16_deviations.json)
+BF16_BANDS = {
+    # measured (cfg 3): bpp_y 1.3e-4, bpp_z 9e-8, bpp_total 1.0e-4, mse 2.8e-5, PSNR 1.2e-4 dB, y 6.4e-3, cosine 0.99998
+    128: {"bpp_y": 3e-4, "bpp_z": 1e-5, "bpp_total": 2.5e-4, "mse": 1e-4, "psnr_db": 5e-4, "y_rel_max": 0.013, "cosine": 0.9999},
+    # measured (cfg 2h): bpp_y 1.3e-4, bpp_z 1.2e-7, bpp_total 1.1e-4, mse 3.4e-4, PSNR 1.5e-3 dB, y 7.2e-3, cosine 0.99997
+    192: {"bpp_y": 3e-4, "bpp_z": 1e-5, "bpp_total": 2.5e-4, "mse": 7e-4, "psnr_db": 3e-3, "y_rel_max": 0.015, "cosine": 0.9999},
+}
+
+
 @pytest.mark.parametrize("M,K", [(128, 3), (192, 1)])
 def test_full_size_bf16_storage_step_vs_torch_cpu_path(env, M, K):
     """Config 3 (JAH(128, K=3), B = 32, 256x256, bf16 storage in the conv/GDN stacks) and config 2's model in
-    the same mode, at full size, against the fp32 torch-CPU path.  Declared tolerances of this mode (not in
-    the reference): bpp within 3 %, mse within 3 %, PSNR within 0.15 dB, every parameter
-    gradient with more than 1e-3 of the largest gradient's norm has cosine >= 0.98 with the fp32 gradient."""
+    the same mode, at full size, against the fp32 torch-CPU path.  The mode is not in the reference, so
+    its tolerances are OURS -- but measured, not declared: the achieved deviations are recorded
+    (profiles/r03_bf16_deviations.json) and the bands are 2x those (BF16_BANDS above): bpp within 3e-4, mse within
+    1e-4 / 7e-4, PSNR within 5e-4 / 3e-3 dB, every parameter gradient with more than 1e-3 of the largest gradient's
+    norm has cosine >= 0.9999 with the fp32 gradient."""
     nic, F_, O, dev = env
     from oracle import torch_ref as TR
     with traced(F_):
         model, st, x, noise, out, res = _full_step(nic, dev, M, K, 32, 256, 256, 700 + M, precision="bf16")
         t_out, t_loss, t_grads = TR.step(st, x, M, K, "5x5", noise, 0.01)
-        for k in ("bpp_y", "bpp_z", "bpp_total", "mse"):
-            assert abs(res[k] - t_loss[k]) <= 0.03 * abs(t_loss[k]), (k, res[k], t_loss[k])
-        assert abs(res["psnr"] - t_loss["psnr"]) <= 0.15, (res["psnr"], t_loss["psnr"])
+        dev_rel = {k: abs(res[k] - t_loss[k]) / abs(t_loss[k]) for k in ("bpp_y", "bpp_z", "bpp_total", "mse")}
+        dpsnr = abs(res["psnr"] - t_loss["psnr"])
         ymax = np.abs(t_out["y"]).max()
-        assert np.abs(host(out["y"]) - t_out["y"]).max() <= 0.03 * ymax
+        dy = float(np.abs(host(out["y"]) - t_out["y"]).max() / ymax)
         norms = {n: float(np.linalg.norm(t_grads[n])) for n, _ in model.named_parameters()}
         big = max(norms.values())
         worst = ("", 1.0)
@@ -437,7 +448,20 @@ def test_full_size_bf16_storage_step_vs_torch_cpu_path(env, M, K):
             cos = float(a @ b / (np.linalg.norm(a) * np.linalg.norm(b) + 1e-300))
             if cos < worst[1]:
                 worst = (n, cos)
-        assert worst[1] >= 0.98, worst
+        # the achieved deviations are recorded (gpurun_out/bf16_deviations_M*.json -> DESIGN.md); the bands below are
+        # 2x what was measured on an MI355X at this size, not free-standing declarations
+        rec = {"M": M, "K": K, "rel": dev_rel, "psnr_db": dpsnr, "y_rel_max": dy, "worst_grad_cosine": worst}
+        out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        if os.path.isdir(out_dir):
+            import json
+            with open(os.path.join(out_dir, f"bf16_deviations_M{M}.json"), "w") as f:
+                json.dump(rec, f, indent=1)
+        band = BF16_BANDS[M]
+        for k, v in dev_rel.items():
+            assert v <= band[k], (k, v, band[k], res[k], t_loss[k])
+        assert dpsnr <= band["psnr_db"], (dpsnr, res["psnr"], t_loss["psnr"])
+        assert dy <= band["y_rel_max"], dy
+        assert worst[1] >= band["cosine"], worst
 
 
 # ---------------------------------------------------------------------------------------------
