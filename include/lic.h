@@ -208,6 +208,9 @@ int lic_gdn_reparam(const float* p, float* out, int64_t n, float bound, float pe
 /* dp = pass ? dout*2*max(p,bound) : 0, pass = (p >= bound) | (that product < 0)  (LowerBound bwd) */
 int lic_gdn_reparam_bwd(const float* p, const float* dout, float* dp, int64_t n, float bound,
                         lic_stream_t stream);
+/* lic_gdn_reparam_bwd for beta [nb] and gamma [ng] of one GDN in one launch (either count may be 0) */
+int lic_gdn_reparam_bwd2(const float* pb, const float* dob, float* dpb, int64_t nb, float bound_b, const float* pg,
+                         const float* dog, float* dpg, int64_t ng, float bound_g, lic_stream_t stream);
 /* t = dL/dnorm: inverse ? 0.5*g*x*rsqrt(n) : -0.5*g*x*rsqrt(n)/n   (dense [n] tensors) */
 int lic_gdn_dnorm(const float* g, const float* x, const float* norm, float* t, int64_t n,
                   int32_t inverse, lic_stream_t stream);
@@ -319,6 +322,9 @@ int lic_im2col_bf16(const float* x, void* col, int32_t B, int32_t H, int32_t W, 
 int lic_col2im_bf16(const void* col, const float* bias, float* out, int32_t B, int32_t Hi, int32_t Wi,
                     int32_t C, int32_t Ho, int32_t Wo, int32_t kh, int32_t kw, int32_t stride, int32_t pad,
                     int32_t Kpad, lic_stream_t stream);
+/* column sums of two bf16 [P][ld] matrices of one shape in one launch pair (workspace: twice the single size) */
+int lic_colsum2_bf16(const void* in_a, const void* in_b, int64_t ld, int64_t P, int32_t C, float scale, float* out_a,
+                     float* out_b, void* workspace, size_t workspace_bytes, lic_stream_t stream);
 size_t lic_colsum_bf16_workspace_bytes(int64_t P, int32_t C);
 int lic_colsum_bf16(const void* in, int64_t ld, int64_t P, int32_t C, float scale, float* out,
                     void* workspace, size_t workspace_bytes, lic_stream_t stream);

@@ -81,6 +81,7 @@ SIGNATURES = {
     "lic_leaky_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp]),
     "lic_gdn_reparam": (C.c_int, [_vp, _vp, _i64, _f32, _f32, _vp]),
     "lic_gdn_reparam_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp]),
+    "lic_gdn_reparam_bwd2": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp, _vp, _vp, _i64, _f32, _vp]),
     "lic_gdn_dnorm": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "lic_quantize": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "lic_entropy_params_fwd": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _vp]),
@@ -113,6 +114,7 @@ SIGNATURES = {
     "lic_col2im_bf16": (C.c_int, [_vp, _vp, _vp] + [_i32] * 11 + [_vp]),
     "lic_colsum_bf16_workspace_bytes": (_sz, [_i64, _i32]),
     "lic_colsum_bf16": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _vp, _vp, _sz, _vp]),
+    "lic_colsum2_bf16": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _f32, _vp, _vp, _vp, _sz, _vp]),
     "lic_gdn_dnorm_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "lic_leaky_bwd_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp]),
     "lic_igemm_fused_gdn_supported": (C.c_int, [_i32, _i32]),

@@ -295,6 +295,23 @@ LIC_EXPORT int lic_gdn_reparam_bwd(const float* p, const float* dout, float* dp,
   });
 }
 
+// the same for the two parameters of one GDN (beta [C], gamma [C][C]) in ONE launch: element i < nb is beta's,
+// the rest gamma's (either half may be absent: n = 0)
+LIC_EXPORT int lic_gdn_reparam_bwd2(const float* pb, const float* dob, float* dpb, int64_t nb, float bound_b,
+                                    const float* pg, const float* dog, float* dpg, int64_t ng, float bound_g,
+                                    lic_stream_t stream) {
+  if (nb < 0 || ng < 0 || (nb > 0 && (!pb || !dob || !dpb)) || (ng > 0 && (!pg || !dog || !dpg))) return LIC_ERR_INVALID;
+  if (nb + ng == 0) return LIC_OK;
+  return ew_launch(nb + ng, stream, [=] __device__(long i) {
+    const bool isb = i < nb;
+    const long j = isb ? i : i - nb;
+    const float pv = isb ? pb[j] : pg[j], dv = isb ? dob[j] : dog[j], bound = isb ? bound_b : bound_g;
+    const float v = pv > bound ? pv : bound;
+    const float g = dv * 2.0f * v;
+    (isb ? dpb : dpg)[j] = (pv >= bound || g < 0.0f) ? g : 0.0f;
+  });
+}
+
 __device__ __forceinline__ float gdn_t1(float g, float x, float n, int inverse) {
   const float rs = __builtin_amdgcn_rsqf(n);  // v_rsq_f32, 1 ulp
   return inverse ? 0.5f * g * x * rs : -0.5f * g * x * rs * (rs * rs);

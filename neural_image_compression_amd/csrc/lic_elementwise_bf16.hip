@@ -92,9 +92,14 @@ LIC_EXPORT int lic_col2im_bf16(const void* col, const float* bias, float* out, i
 }
 
 // column sums of a bf16 [P][ld] matrix -> fp32, two deterministic stages (C % 8 == 0)
-__global__ __launch_bounds__(256) void colsum_bf16_stage1(const bf16_t* in, long ld, long P, int C, float* part,
-                                                          int nchunk) {
+// (blockIdx.z = 1: the second matrix of lic_colsum2_bf16 -- same shape, its partials behind the first's)
+__global__ __launch_bounds__(256) void colsum_bf16_stage1(const bf16_t* in, const bf16_t* in2, long ld, long P, int C,
+                                                          float* part, int nchunk) {
   __shared__ float red[32][64 + 4];
+  if (blockIdx.z) {
+    in = in2;
+    part += (long)nchunk * C;
+  }
   const int cg = threadIdx.x & 7, ry = threadIdx.x >> 3;  // 8 column octets x 32 row lanes
   const int c = blockIdx.x * 64 + cg * 8;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -116,8 +121,12 @@ __global__ __launch_bounds__(256) void colsum_bf16_stage1(const bf16_t* in, long
   }
 }
 __global__ __launch_bounds__(256) void colsum_bf16_stage2(const float* part, int C, int nchunk, float scale,
-                                                          float* out) {
+                                                          float* out, float* out2) {
   __shared__ double red[16][17];
+  if (blockIdx.z) {
+    out = out2;
+    part += (long)nchunk * C;
+  }
   const int cx = threadIdx.x & 15, ly = threadIdx.x >> 4;
   const int c = blockIdx.x * 16 + cx;
   double acc = 0.0;
@@ -149,12 +158,30 @@ LIC_EXPORT int lic_colsum_bf16(const void* in, int64_t ld, int64_t P, int32_t C,
   const int nchunk = csh_chunks(P);
   if (workspace_bytes < (size_t)nchunk * C * sizeof(float)) return LIC_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(colsum_bf16_stage1, dim3((C + 63) / 64, nchunk), dim3(256), 0, s, (const bf16_t*)in, (long)ld,
-                     (long)P, C, (float*)workspace, nchunk);
+  hipLaunchKernelGGL(colsum_bf16_stage1, dim3((C + 63) / 64, nchunk), dim3(256), 0, s, (const bf16_t*)in,
+                     (const bf16_t*)nullptr, (long)ld, (long)P, C, (float*)workspace, nchunk);
   int rc = lic_check_launch();
   if (rc != LIC_OK) return rc;
   hipLaunchKernelGGL(colsum_bf16_stage2, dim3((C + 15) / 16), dim3(256), 0, s, (const float*)workspace, C, nchunk,
-                     scale, out);
+                     scale, out, (float*)nullptr);
+  return lic_check_launch();
+}
+// column sums of TWO bf16 [P][ld] matrices of one shape in one launch pair (the d-beta and d-bias sums of a
+// conv -> GDN pair's backward: t = dL/dnorm and dL/d(conv output)); workspace: 2 x lic_colsum_bf16_workspace_bytes
+LIC_EXPORT int lic_colsum2_bf16(const void* in_a, const void* in_b, int64_t ld, int64_t P, int32_t C, float scale,
+                                float* out_a, float* out_b, void* workspace, size_t workspace_bytes, lic_stream_t stream) {
+  if (!in_a || !in_b || !out_a || !out_b || !workspace || P <= 0 || C <= 0) return LIC_ERR_INVALID;
+  if (C % 8 || ld % 8 || (reinterpret_cast<uintptr_t>(in_a) & 15) || (reinterpret_cast<uintptr_t>(in_b) & 15))
+    return LIC_ERR_UNSUPPORTED;
+  const int nchunk = csh_chunks(P);
+  if (workspace_bytes < 2 * (size_t)nchunk * C * sizeof(float)) return LIC_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(colsum_bf16_stage1, dim3((C + 63) / 64, nchunk, 2), dim3(256), 0, s, (const bf16_t*)in_a,
+                     (const bf16_t*)in_b, (long)ld, (long)P, C, (float*)workspace, nchunk);
+  int rc = lic_check_launch();
+  if (rc != LIC_OK) return rc;
+  hipLaunchKernelGGL(colsum_bf16_stage2, dim3((C + 15) / 16, 1, 2), dim3(256), 0, s, (const float*)workspace, C, nchunk,
+                     scale, out_a, out_b);
   return lic_check_launch();
 }
 

@@ -248,6 +248,20 @@ def grad_like(param: torch.Tensor) -> torch.Tensor:
     return torch.empty_like(param, memory_format=torch.contiguous_format)
 
 
+def _reparam_bwd2(beta_c, dbe, beta_bound, gamma_c, dge, gamma_bound):
+    """gradients of beta / gamma through compressai's NonNegativeParametrizer from the gradients
+    of beta_eff / gamma_eff: both parameters of a GDN in one launch"""
+    dbeta = torch.empty_like(beta_c) if beta_c is not None else None
+    dgamma = torch.empty_like(gamma_c) if gamma_c is not None else None
+    if dbeta is None and dgamma is None:
+        return None, None
+    L.check(L.load().lic_gdn_reparam_bwd2(_ptr(beta_c), _ptr(dbe), _ptr(dbeta), 0 if dbeta is None else dbeta.numel(),
+                                          beta_bound, _ptr(gamma_c), _ptr(dge), _ptr(dgamma),
+                                          0 if dgamma is None else dgamma.numel(), gamma_bound, _stream()),
+            "lic_gdn_reparam_bwd2")
+    return dbeta, dgamma
+
+
 def _leaky_bwd(y, dy, slope):
     dx = torch.empty_like(y)
     L.check(L.load().lic_leaky_bwd(_ptr(y), _ptr(dy), _ptr(dx), y.numel(), slope, _stream()),
@@ -757,19 +771,15 @@ def _gdn_backward(xh, norm, beta, gamma, g, inverse, beta_bound, gamma_bound, pe
             _igemm(t, gp, dxh, B=1, Hi=1, Wi=P, Cin=Cc, Ho=1, Wo=P, Cout=Cc, kh=1, kw=1,
                    stride=1, pad=0, transposed=False, epilogue=L.EPI_IGDN_BWD if inverse else L.EPI_GDN_BWD,
                    aux=g, aux2=xh, aux3=norm)
-    if need_dbeta:
-        if dbe is None:
-            dbe = _colsum(t, P, Cc)
-        dbeta = torch.empty_like(beta_c)
-        L.check(lib.lic_gdn_reparam_bwd(_ptr(beta_c), _ptr(dbe), _ptr(dbeta), Cc, beta_bound,
-                                        _stream()), "lic_gdn_reparam_bwd")
+    dge = None
+    if need_dbeta and dbe is None:
+        dbe = _colsum(t, P, Cc)
     if need_dgamma:
         dge = torch.empty_like(gamma_c)
         _wgrad(t, xh, dge, B=1, Hs=1, Ws=P, Cp=Cc, Hl=1, Wl=P, Cg=Cc, kh=1, kw=1, stride=1, pad=0,
                g_is_row=False, dst_sm=Cc, dst_sn=1, dst_stap=0, sq_g=1)
-        dgamma = torch.empty_like(gamma_c)
-        L.check(lib.lic_gdn_reparam_bwd(_ptr(gamma_c), _ptr(dge), _ptr(dgamma), Cc * Cc, gamma_bound,
-                                        _stream()), "lic_gdn_reparam_bwd")
+    dbeta, dgamma = _reparam_bwd2(beta_c if need_dbeta else None, dbe, beta_bound,
+                                  gamma_c if need_dgamma else None, dge, gamma_bound)
     if cs_dx is not None and dxh is not None:
         dxh._lic_colsum_partial = cs_dx  # [rows][C] partial column sums of dx: the conv in front needs only these
     return dxh, dbeta, dgamma

@@ -13,8 +13,8 @@ import ctypes as C
 import torch
 
 from . import _lib as L
-from .functional import (PEDESTAL, _colsum, _nchw_view, _nhwc, _permute3, _ptr, _stream, conv_out_size, grad_like,
-                         prepared)
+from .functional import (PEDESTAL, _colsum, _nchw_view, _nhwc, _permute3, _ptr, _reparam_bwd2, _stream, conv_out_size,
+                         grad_like, prepared)
 
 BF16 = torch.bfloat16
 _NAMES = {}      # geometry -> kernel variant name (bench.py's event brackets)
@@ -143,6 +143,17 @@ def _colsum_bf16(t2d, P, Cc):
     L.check(lib.lic_colsum_bf16(_ptr(t2d), Cc, P, Cc, 1.0, _ptr(out), _ptr(ws), nbytes, _stream()),
             "lic_colsum_bf16")
     return out
+
+
+def _colsum2_bf16(a2d, b2d, P, Cc):
+    """column sums of two bf16 [P][Cc] matrices in one launch pair"""
+    lib = L.load()
+    nbytes = 2 * lib.lic_colsum_bf16_workspace_bytes(P, Cc)
+    ws = torch.empty((nbytes + 3) // 4, device=a2d.device, dtype=torch.float32)
+    out = torch.empty((2, Cc), device=a2d.device, dtype=torch.float32)
+    L.check(lib.lic_colsum2_bf16(_ptr(a2d), _ptr(b2d), Cc, P, Cc, 1.0, _ptr(out[0]), _ptr(out[1]), _ptr(ws), nbytes,
+                                 _stream()), "lic_colsum2_bf16")
+    return out[0], out[1]
 
 
 def _leaky_bwd_bf16(y, dy, slope):
@@ -398,9 +409,10 @@ def _gdn_operands_bf16(beta, gamma, beta_bound, gamma_bound, pedestal, kperm=Fal
 
 
 def _gdn_backward_bf16(xh, norm, beta, gamma, g, inverse, beta_bound, gamma_bound, pedestal, need_dx, need_dbeta,
-                       need_dgamma):
+                       need_dgamma, bias_from_dx=False):
     """gradients of y = x * norm^-1/2 (or ^1/2), norm = beta_eff + x^2 . gamma_eff^T, from g = dL/dy (bf16 NHWC);
-    dx comes back as a bf16 NHWC tensor"""
+    dx comes back as a bf16 NHWC tensor.  `bias_from_dx`: also return the column sums of dx -- the bias gradient of
+    the convolution in front -- from the same launch pair as d-beta's (a 4th result)"""
     beta_c, gamma_c = beta.contiguous(), gamma.contiguous()
     lib = L.load()
     B, H, W, Cc = xh.shape
@@ -417,18 +429,19 @@ def _gdn_backward_bf16(xh, norm, beta, gamma, g, inverse, beta_bound, gamma_boun
         _igemm_bf16(t, gp, dxh, B=1, Hi=1, Wi=P, Cin=Cc, Ho=1, Wo=P, Cout=Cc,
                     kh=1, kw=1, stride=1, pad=0, transposed=False,
                     epilogue=L.EPI_IGDN_BWD if inverse else L.EPI_GDN_BWD, aux=g, aux2=xh, aux3=norm)
-    if need_dbeta:
+    dbe = dge = db_conv = None
+    if bias_from_dx and need_dbeta and dxh is not None:
+        dbe, db_conv = _colsum2_bf16(t, dxh, P, Cc)
+    elif need_dbeta:
         dbe = _colsum_bf16(t, P, Cc)
-        dbeta = torch.empty_like(beta_c)
-        L.check(lib.lic_gdn_reparam_bwd(_ptr(beta_c), _ptr(dbe), _ptr(dbeta), Cc, beta_bound, _stream()),
-                "lic_gdn_reparam_bwd")
     if need_dgamma:
         dge = torch.empty_like(gamma_c)
         _wgrad_bf16(t, xh, dge, B=1, Hs=1, Ws=P, Cp=Cc, Hl=1, Wl=P, Cg=Cc, kh=1, kw=1, stride=1, pad=0,
                     g_is_row=False, dst_sm=Cc, dst_sn=1, dst_stap=0, sq_g=1)
-        dgamma = torch.empty_like(gamma_c)
-        L.check(lib.lic_gdn_reparam_bwd(_ptr(gamma_c), _ptr(dge), _ptr(dgamma), Cc * Cc, gamma_bound, _stream()),
-                "lic_gdn_reparam_bwd")
+    dbeta, dgamma = _reparam_bwd2(beta_c if need_dbeta else None, dbe, beta_bound,
+                                  gamma_c if need_dgamma else None, dge, gamma_bound)
+    if bias_from_dx:
+        return dxh, dbeta, dgamma, db_conv
     return dxh, dbeta, dgamma
 
 
@@ -503,16 +516,21 @@ class _ConvGDNBF16Fn(torch.autograd.Function):
         (stride, pad, transposed, inverse, beta_bound, gamma_bound, pedestal, has_bias, in_dtype, stem, Cin,
          direct) = ctx.cfg
         need = ctx.needs_input_grad
-        g_conv, dbeta, dgamma = _gdn_backward_bf16(conv_out, norm, beta, gamma, _as_bf16_nhwc(gy), inverse, beta_bound,
-                                                   gamma_bound, pedestal, True, need[3], need[4])
+        want_db = has_bias and need[2]
+        g_conv, dbeta, dgamma, db_pre = _gdn_backward_bf16(conv_out, norm, beta, gamma, _as_bf16_nhwc(gy), inverse,
+                                                           beta_bound, gamma_bound, pedestal, True, need[3], need[4],
+                                                           bias_from_dx=want_db)
         if direct and (need[1] or (has_bias and need[2])):   # src is the image: its columns for the weight gradient
             src = _stem_columns_bf16(_nchw_view(src), weight, stride, pad)[0]
+        # (the bias gradient = column sums of g_conv: already there when it shared d-beta's launch pair)
         if stem:
             dx = None
-            dw, db = _stem_backward_bf16(src, weight, g_conv, Cin, need[1], has_bias and need[2])
+            dw, db = _stem_backward_bf16(src, weight, g_conv, Cin, need[1], want_db and db_pre is None)
         else:
             dx, dw, db = _conv_backward_bf16(src, weight, g_conv, stride, pad, transposed, in_dtype, 0, need[0], need[1],
-                                             has_bias and need[2])
+                                             want_db and db_pre is None)
+        if db_pre is not None:
+            db = db_pre
         return dx, dw, db, dbeta, dgamma, None, None, None, None, None, None, None, None, None
 
 
