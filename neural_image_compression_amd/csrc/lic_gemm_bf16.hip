@@ -630,6 +630,7 @@ __global__ __launch_bounds__(256) void igemm_bf16_finish_kernel(const float* sla
 }
 
 #include "lic_halo_bf16.h"
+#include "lic_halot_bf16.h"
 
 #ifdef LIC_HALO_ABLATE
 LIC_EXPORT int lic_halo_debug_read(void* dst, size_t bytes) {
@@ -829,6 +830,28 @@ static int igemmh_prepare(const lic_igemm_desc* d, int32_t out_f32, IgemmHParams
     const int htx = (d->Wo + halo::TWD - 1) / halo::TWD, hty = (d->Ho + halo::TH - 1) / halo::TH;
     const char* e = getenv("LIC_BF16_HALO");  // tuning aid: 0 = never
     const bool off = e && e[0] == '0';
+    // ... and the transposed layers (ConvTranspose2d forward, data gradient of the strided convolution): BM = 513,
+    // tiles of 8 x 32 phase pixels (lic_halot_bf16.h)
+    const bool shape_t = p.transposed && d->kh == 5 && d->kw == 5 && d->stride == 2 && d->pad == 2 &&
+                         (d->tap_mask == 0 || (d->tap_mask & 0x1FFFFFFu) == 0x1FFFFFFu) && d->prologue == 0 &&
+                         (((epi == LIC_EPI_NONE || epi == LIC_EPI_LEAKY) && !d->out2) || (fuse && !out_f32)) && d->Cin % 64 == 0 &&
+                         d->Cout == 128 && d->Ho == 2 * d->Hi && d->Wo == 2 * d->Wi &&
+                         (long)d->B * d->Hi * d->Wi * d->in_ld < 0x7FFFFFFFL;
+    const int qtx = (d->Wi + halot::TWD - 1) / halot::TWD, qty = (d->Hi + halot::TH - 1) / halot::TH;
+    if (shape_t && (d->force_bm == 512 || (!d->force_bm && !off && qtx * qty >= 4))) {
+      BM = 513;
+      p.htx = qtx;
+      p.hty = qty;
+      p.MT = d->B * qtx * qty;
+      p.NT = 1;
+      p.pgroup = p.porder = 0;
+      p.ksplit = 1;
+      p.cps = 0;
+      p.slabs = nullptr;
+      p.ring = 0;
+      nwg = p.MT;
+      return LIC_OK;
+    }
     if (shape_ok && (d->force_bm == 512 || (!d->force_bm && !off && htx * hty >= 4))) {
       BM = 512;
       p.htx = htx;
@@ -925,6 +948,11 @@ LIC_EXPORT int lic_igemm_bf16_kernel_name(const lic_igemm_desc* d, char* buf, si
   const int rc = igemmh_prepare(d, 0, p, BM, TN, nwg);
   if (rc < 0) return rc;
   if (!buf || n == 0) return LIC_ERR_INVALID;
+  if (BM == 513) {
+    snprintf(buf, n, "halo_convt_bf16_kernel<%d, %s>", p.Npad / 64,
+             (p.epilogue == LIC_EPI_CONV_GDN || p.epilogue == LIC_EPI_CONV_IGDN) ? "true" : "false");
+    return LIC_OK;
+  }
   if (BM == 512) {
     snprintf(buf, n, "halo_conv_bf16_kernel<%d, %s, 0>", p.Npad / 64,
              (p.epilogue == LIC_EPI_CONV_GDN || p.epilogue == LIC_EPI_CONV_IGDN) ? "true" : "false");
@@ -947,7 +975,7 @@ LIC_EXPORT int lic_igemm_bf16(const lic_igemm_desc* d, int32_t out_f32, lic_stre
   hipStream_t s = (hipStream_t)stream;
   dim3 grid((unsigned)nwg), block(256);
   const bool fuse = p.epilogue == LIC_EPI_CONV_GDN || p.epilogue == LIC_EPI_CONV_IGDN;
-  if (BM == 512) {  // halo-resident 5x5 stride-2 variant: persistent workgroups, one per CU
+  if (BM == 512 || BM == 513) {  // halo-resident 5x5 stride-2 variants: persistent workgroups, one per CU
     static int ncu = 0;
     if (!ncu) {
       int dev = 0, n = 0;
@@ -969,6 +997,11 @@ LIC_EXPORT int lic_igemm_bf16(const lic_igemm_desc* d, int32_t out_f32, lic_stre
 #endif
     // (a 192-channel instance, 128 x 96 per wave, compiles but needs more than the 256 + 256 registers: hipcc moves
     // fragments that are still in flight; not dispatched)
+    if (BM == 513) {
+      if (fuse) hipLaunchKernelGGL((halo_convt_bf16_kernel<2, true>), grid, block, 0, s, p);
+      else hipLaunchKernelGGL((halo_convt_bf16_kernel<2>), grid, block, 0, s, p);
+      return lic_check_launch();
+    }
     if (fuse) hipLaunchKernelGGL((halo_conv_bf16_kernel<2, true>), grid, block, 0, s, p);
     else hipLaunchKernelGGL((halo_conv_bf16_kernel<2>), grid, block, 0, s, p);
     return lic_check_launch();

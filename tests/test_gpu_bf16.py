@@ -162,6 +162,24 @@ def test_halo_conv_forced_onto_small_ragged_shapes(env, ci, co, H, W, B):
     assert "halo_conv_bf16_kernel<2, false, 0>" in names, names
 
 
+@pytest.mark.parametrize("ci,co,H,W,B", [(128, 128, 19, 37, 2),    # partial q tiles in both directions
+                                          (64, 128, 8, 8, 3),       # 2 chunks: one trip of every phase body
+                                          (192, 128, 5, 40, 1),     # 6 chunks, two column tiles
+                                          (128, 128, 1, 1, 2)])     # a tile that is almost all padding
+def test_halo_transposed_conv_forced_onto_small_ragged_shapes(env, ci, co, H, W, B):
+    """the transposed halo kernel (lic_halot_bf16.h: four phases on one resident input patch) forced onto small ragged
+    shapes, forward and backward against the oracle (with ci = 128 the data gradient runs the strided halo kernel)"""
+    nic, FB, O, d = env
+    from neural_image_compression_amd import functional as F_
+    names = set()
+    F_.FORCE_IGEMM, F_.KERNEL_TRACE = (512, 0, 1), names
+    try:
+        _conv_bf16_ops(env, 5, 2, 2, ci, co, H, W, B, True, 1)
+    finally:
+        F_.FORCE_IGEMM, F_.KERNEL_TRACE = None, None
+    assert "halo_convt_bf16_kernel<2, false>" in names, names
+
+
 def test_halo_conv_at_full_size_beside_a_second_stream(env):
     """The halo kernel hands LDS buffers from the DMA to the fragment reads with counted `vmcnt` waits and ONE barrier
     per channel chunk, and keeps weight fragments in flight in registers: a mistake there is a race that small quiet
@@ -173,12 +191,15 @@ def test_halo_conv_at_full_size_beside_a_second_stream(env):
     from neural_image_compression_amd import functional as F_
     g = torch.Generator(device="cpu").manual_seed(11)
     x = torch.randn(32, 128, 128, 128, generator=g).to(d).contiguous(memory_format=torch.channels_last).to(BF)
+    xs = torch.randn(32, 128, 64, 64, generator=g).to(d).contiguous(memory_format=torch.channels_last).to(BF)
     w = (torch.randn(128, 128, 5, 5, generator=g) / 56.0).to(d)
     b = torch.randn(128, generator=g).to(d)
     a = torch.randn(4096, 4096, device=d, dtype=BF)
     side = torch.cuda.Stream()
     fns = [lambda: FB.conv2d_bf16(x, w, b, 2, 2), lambda: FB.conv2d_bf16(x, w, b, 2, 2, leaky=True, slope=0.01),
-           lambda: FB.conv2d_bf16(x, w, b, 2, 2, out_f32=True)]
+           lambda: FB.conv2d_bf16(x, w, b, 2, 2, out_f32=True),
+           lambda: FB.conv_transpose2d_bf16(xs, w, b, 2, 2, 1),          # the transposed halo kernel, 512 tiles
+           lambda: FB.conv_transpose2d_bf16(xs, w, b, 2, 2, 1, out_f32=True)]
     names = set()
     with torch.no_grad():
         F_.FORCE_IGEMM = (128, 0, 1)
@@ -204,7 +225,7 @@ def test_halo_conv_at_full_size_beside_a_second_stream(env):
                         assert torch.equal(o, f0), f"iteration {it}: the halo kernel is not bit-repeatable"
         finally:
             F_.FORCE_IGEMM, F_.KERNEL_TRACE = None, None
-    assert names == {"halo_conv_bf16_kernel<2, false, 0>"}, names
+    assert names == {"halo_conv_bf16_kernel<2, false, 0>", "halo_convt_bf16_kernel<2, false>"}, names
 
 
 def test_dispatched_eight_wave_tiles_at_full_size_beside_a_second_stream(env):
@@ -439,6 +460,8 @@ def test_gdn_bf16(env, inverse):
     (5, 2, 2, 64, 128, 37, 45, 2, False, 0, False, 512),  # the halo-resident kernel with the fused pool: partial tiles
     (5, 2, 2, 128, 128, 64, 64, 3, False, 0, False, 512), # ... four full tiles per image, two per workgroup and more
     (5, 2, 2, 192, 128, 16, 20, 2, False, 0, True, 512),  # ... six chunks, IGDN
+    (5, 2, 2, 64, 128, 19, 21, 2, True, 1, True, 512),    # the transposed halo kernel with the fused pool (IGDN)
+    (5, 2, 2, 128, 128, 32, 32, 2, True, 1, False, 512),  # ... four full tiles per image, GDN
 ])
 def test_conv_gdn_fused_bf16_matches_two_launches(env, k, s, p, ci, co, H, W, B, tr, op, inverse, bm):
     nic, FB, O, d = env
@@ -490,6 +513,8 @@ def test_conv_gdn_fused_bf16_matches_two_launches(env, k, s, p, ci, co, H, W, B,
     tn = co // 64
     if stem and (k, s, p) == (5, 2, 2):
         assert f"stem_gdn_bf16_kernel<{co // 32}, {8 if co == 192 else 4}>" in names, names
+    elif bm == 512 and tr:
+        assert "halo_convt_bf16_kernel<2, true>" in names and "halo_convt_bf16_kernel<2, false>" in names, names
     elif bm == 512:
         assert "halo_conv_bf16_kernel<2, true, 0>" in names and "halo_conv_bf16_kernel<2, false, 0>" in names, names
     else:

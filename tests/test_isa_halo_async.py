@@ -66,10 +66,10 @@ def _kernels_with_addresses(tmp_path, pattern):
     return out
 
 
-def _body(insns):
-    """(start index, [(mnemonic, operands)]) of the innermost loop with the most MFMAs: from the target of a backward
-    branch to that branch, with no other control flow inside"""
-    best = (0, [])
+def _loops(insns):
+    """[(start index, [(mnemonic, operands)])] of every innermost loop (from the target of a backward branch to that
+    branch, no other control flow inside), most MFMAs first"""
+    out = []
     index = {a: i for i, (a, _, _, _) in enumerate(insns)}
     for i, (addr, mn, ops, tgt) in enumerate(insns):
         if tgt is None or tgt > addr or tgt not in index:
@@ -78,9 +78,13 @@ def _body(insns):
         seg = insns[j:i]
         if any(m.startswith(CTRL) for _, m, _, _ in seg):
             continue
-        if sum(m.startswith("v_mfma") for _, m, _, _ in seg) > sum(m.startswith("v_mfma") for m, _ in best[1]):
-            best = (j, [(m, o) for _, m, o, _ in seg])
-    return best
+        out.append((j, [(m, o) for _, m, o, _ in seg]))
+    out.sort(key=lambda b: -sum(m.startswith("v_mfma") for m, _ in b[1]))
+    return out
+
+
+def _body(insns):
+    return _loops(insns)[0]
 
 
 def _audit_loads(body):
@@ -110,9 +114,26 @@ def _audit_loads(body):
 
 @pytest.mark.skipif(not os.path.exists(OBJDUMP), reason="needs ROCm's llvm-objdump")
 def test_halo_kernel_async_registers(tmp_path):
-    kernels = _kernels_with_addresses(tmp_path, "halo_conv_bf16_kernel")
-    names = list(kernels)
+    kernels = _kernels_with_addresses(tmp_path, "halo_conv")
+    names = [k for k in kernels if "halo_conv_bf16_kernel" in k]
     assert names, "halo_conv_bf16_kernel was not found in the library"
+    # the transposed kernel: four phase loops (two-chunk bodies of 18 / 12 / 12 / 8 steps); each is audited for spill
+    # code and for the coverage of its weight loads
+    tnames = [k for k in kernels if "halo_convt_bf16_kernel" in k]
+    assert tnames, "halo_convt_bf16_kernel was not found in the library"
+    for name in tnames:
+        loops = [b for _, b in _loops(kernels[name]) if sum(m.startswith("v_mfma") for m, _ in b) >= 100]
+        assert sorted(sum(m.startswith("v_mfma") for m, _ in b) for b in loops) == [128, 192, 192, 288], name
+        for body in loops:
+            mn = [m for m, _ in body]
+            steps = mn.count("v_mfma_f32_32x32x16_bf16") // 16
+            assert mn.count("ds_read_b128") == 8 * steps and mn.count("global_load_dwordx4") == 4 * steps
+            assert mn.count("buffer_load_dwordx4") == 12 and mn.count("s_barrier") == 2
+            spill = [m for m in mn if m.startswith("scratch_") or m.startswith("v_accvgpr")]
+            assert not spill, f"{name}: spill code inside a tap loop: {spill[:5]}"
+            checked, bad = _audit_loads(body)
+            assert not bad, "\n".join(bad[:10])
+            assert checked == 4 * steps, checked
     for name in names:
         insns = kernels[name]
         start, body = _body(insns)

@@ -29,25 +29,26 @@ def timeit(fn, reps=20):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-def run(B, M, H, W, force):
+def run(B, M, H, W, force, transposed=False):
     g = torch.Generator(device="cpu").manual_seed(H * 7 + M)
     x = torch.randn(B, M, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last).to(BF)
     w = (torch.randn(M, M, 5, 5, generator=g) / (5.0 * M ** 0.5)).to(dev)
     b = torch.randn(M, generator=g).to(dev)
     outs, times = {}, {}
+    fn = (lambda: FB.conv_transpose2d_bf16(x, w, b, 2, 2, 1)) if transposed else (lambda: FB.conv2d_bf16(x, w, b, 2, 2))
     for name, f in force.items():
         F_.FORCE_IGEMM = f
         try:
             with torch.no_grad():
-                outs[name] = FB.conv2d_bf16(x, w, b, 2, 2).float()
-            times[name] = timeit(lambda: FB.conv2d_bf16(x, w, b, 2, 2))
+                outs[name] = fn().float()
+            times[name] = timeit(fn)
         finally:
             F_.FORCE_IGEMM = None
     ref = outs["igemm128"]
-    flop = 2.0 * B * ((H + 1) // 2) * ((W + 1) // 2) * 25 * M * M
+    flop = 2.0 * B * H * W * 25 * M * M if transposed else 2.0 * B * ((H + 1) // 2) * ((W + 1) // 2) * 25 * M * M
     for name in outs:
         err = (outs[name] - ref).abs().max().item()
-        print(f"B={B} M={M} {H}x{W} {name:10s} {times[name]:8.1f} us {flop / times[name] * 1e-6:8.1f} TF  "
+        print(f"{'convT' if transposed else 'conv '} B={B} M={M} {H}x{W} {name:10s} {times[name]:8.1f} us {flop / times[name] * 1e-6:8.1f} TF  "
               f"max|d| vs igemm128 {err:.3e} (scale {ref.abs().max().item():.2f})", flush=True)
 
 
@@ -58,3 +59,5 @@ if __name__ == "__main__":
     for M in Ms:
         run(32, M, 128, 128, force)
         run(32, M, 64, 64, force)
+        run(32, M, 64, 64, force, transposed=True)
+        run(32, M, 32, 32, force, transposed=True)
