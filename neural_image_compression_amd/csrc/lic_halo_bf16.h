@@ -377,6 +377,24 @@ __global__ __launch_bounds__(256, 1) void halo_conv_bf16_kernel(const IgemmHPara
           for (int g = 0; g < 4; ++g)
             bs[t][g] = *reinterpret_cast<const f32x4*>(p.bias + (wno * TW + t) * 32 + 4 * lho + 8 * g);
       }
+      // (gamma_eff^T fragments and beta_eff are requested NOW, all at once: a load in front of each pool MFMA /
+      // each finish tile was one exposed L2 round trip after the other at one wave per SIMD -- the fused epilogue
+      // took 14 us per tile that way)
+      const bf16_t* gA = p.aux + lane * 8;
+      const int ntile = p.Npad >> 5;
+      bf16x8 gfr[2 * TW][2][TW];
+#pragma unroll
+      for (int tt = 0; tt < 2 * TW; ++tt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+          for (int t = 0; t < TW; ++t)
+            gfr[tt][s2][t] = *reinterpret_cast<const bf16x8*>(gA + ((long)tt * ntile + (wno * TW + t)) * 1024 + s2 * 512);
+      f32x4 be[TW][4];
+#pragma unroll
+      for (int t = 0; t < TW; ++t)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) be[t][g] = *reinterpret_cast<const f32x4*>(p.beta + (wno * TW + t) * 32 + 4 * lho + 8 * g);
       // 1. x -> bf16 (kept in the accumulators as the rounded value), x^2 -> bf16 -> LDS; the conv output if asked for
 #pragma unroll
       for (int a = 0; a < 4; ++a) {
@@ -407,8 +425,6 @@ __global__ __launch_bounds__(256, 1) void halo_conv_bf16_kernel(const IgemmHPara
       }
       __syncthreads();
       // 2. + 3. two row tiles at a time (register budget): pool over all 2 TW input channel tiles, then finish
-      const bf16_t* gA = p.aux + lane * 8;
-      const int ntile = p.Npad >> 5;
 #pragma unroll
       for (int hh = 0; hh < 2; ++hh) {
         f32x16 nacc[2][TW];
@@ -427,7 +443,7 @@ __global__ __launch_bounds__(256, 1) void halo_conv_bf16_kernel(const IgemmHPara
             for (int a2 = 0; a2 < 2; ++a2) b2[a2] = *reinterpret_cast<const bf16x8*>(frag_at(wmo, 2 * hh + a2, tt, s2));
 #pragma unroll
             for (int t = 0; t < TW; ++t) {
-              const bf16x8 a2f = *reinterpret_cast<const bf16x8*>(gA + ((long)tt * ntile + (wno * TW + t)) * 1024 + s2 * 512);
+              const bf16x8 a2f = gfr[tt][s2][t];
 #pragma unroll
               for (int a2 = 0; a2 < 2; ++a2)
                 nacc[a2][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2f, b2[a2], nacc[a2][t], 0, 0, 0);
@@ -445,10 +461,9 @@ __global__ __launch_bounds__(256, 1) void halo_conv_bf16_kernel(const IgemmHPara
             unsigned npk[8], ypk[8];
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-              const f32x4 be = *reinterpret_cast<const f32x4*>(p.beta + cb + 4 * lho + 8 * g);
-#pragma unroll
+              #pragma unroll
               for (int h = 0; h < 2; ++h) {
-                const f32x2 nv = {nacc[a2][t][4 * g + 2 * h] + be[2 * h], nacc[a2][t][4 * g + 2 * h + 1] + be[2 * h + 1]};
+                const f32x2 nv = {nacc[a2][t][4 * g + 2 * h] + be[t][g][2 * h], nacc[a2][t][4 * g + 2 * h + 1] + be[t][g][2 * h + 1]};
                 npk[2 * g + h] = pack2(nv);
                 const f32x2 f = {inv ? __builtin_amdgcn_sqrtf(nv[0]) : __builtin_amdgcn_rsqf(nv[0]),
                                  inv ? __builtin_amdgcn_sqrtf(nv[1]) : __builtin_amdgcn_rsqf(nv[1])};
