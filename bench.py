@@ -295,11 +295,14 @@ def main():
                 import glob
                 suffix = {"2": "", "3": "_cfg3"}[args.config]   # (KeyError -> no committed PMC passes for this config)
                 newest = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_pmc_traffic{suffix}.json")))[-1]
-                pmc = json.load(open(newest))["kernels"]
+                pmc_file = json.load(open(newest))
+                pmc = pmc_file["kernels"]
                 for kname, v in pmc.items():
                     if dom in kname:
                         traffic = v["traffic_bytes_per_launch"]
-                        traffic_src = os.path.relpath(newest, ROOT)
+                        # which committed passes the figure comes from, and when / at which commit they were folded
+                        traffic_src = (f"{os.path.relpath(newest, ROOT)} (measured {pmc_file.get('_date', 'date not recorded')}, "
+                                       f"folded at commit {pmc_file.get('_commit', 'not recorded')})")
             except Exception:
                 traffic = None
             peak = BF16_MFMA_PEAK_TF if "bf16" in dom else FP32_MFMA_PEAK_TF
