@@ -322,6 +322,13 @@ int lic_im2col_bf16(const float* x, void* col, int32_t B, int32_t H, int32_t W, 
 int lic_col2im_bf16(const void* col, const float* bias, float* out, int32_t B, int32_t Hi, int32_t Wi,
                     int32_t C, int32_t Ho, int32_t Wo, int32_t kh, int32_t kw, int32_t stride, int32_t pad,
                     int32_t Kpad, lic_stream_t stream);
+/* GDN / IGDN backward in bf16 storage as one sweep (replaces lic_gdn_dnorm_bf16 + lic_igemm_bf16(EPI_GDN_BWD) for
+ * C in {64, 128}; compressai GDN at Components.py:11-44): t = dL/dnorm (written: the d-gamma / d-beta launches read
+ * it), dx = g * norm^-1/2 + 2 x (t . gamma_eff) (inverse: norm^+1/2).  g, x, norm, dx, t: dense bf16 [P][C];
+ * gamma_packed = lic_pack_weight_bf16_kperm(gamma_eff, taps 1, K = C, N = C, s_k = C, s_n = 1). */
+int lic_gdn_bwd_bf16_supported(int32_t C);
+int lic_gdn_bwd_bf16(const void* g, const void* x, const void* norm, const void* gamma_packed, void* dx, void* t,
+                     int64_t P, int32_t C, int32_t inverse, lic_stream_t stream);
 /* column sums of two bf16 [P][ld] matrices of one shape in one launch pair (workspace: twice the single size) */
 int lic_colsum2_bf16(const void* in_a, const void* in_b, int64_t ld, int64_t P, int32_t C, float scale, float* out_a,
                      float* out_b, void* workspace, size_t workspace_bytes, lic_stream_t stream);

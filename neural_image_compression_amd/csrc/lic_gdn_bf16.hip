@@ -1,0 +1,157 @@
+// GDN / IGDN backward in bf16 storage as ONE sweep (compressai GDN at Components.py:11-44; definition SURVEY.md
+// Appendix B):   t = dL/dnorm(g, x, norm),   dx = g * norm^-1/2 + 2 x (t . gamma_eff)      (IGDN: norm^+1/2)
+//
+// The two-launch route (lic_gdn_dnorm_bf16, then lic_igemm_bf16 with the GDN_BWD epilogue) moves g, x and norm
+// through HBM twice and t three times: 1.2 GB at 128^2 x 32 x 128 channels for a C x C contraction of 17 GFLOP -- the
+// launches are memory-bound, not matrix-bound.  Here a wave owns 32 pixels x all C channels, reads g, x, norm ONCE
+// (16 bytes per lane: pixel = lane & 31, 8 consecutive channels per 16-channel group and lane half), forms t in
+// registers, turns its packed pairs into the MFMA B operand with one v_permlane32_swap per dword pair (the K order
+// of lic_pack_weight_bf16_kperm: the inverse of the fused conv+GDN kernels' store swap), contracts it against
+// gamma_eff (staged once per workgroup in LDS, kperm-packed) with the operands swapped -- the accumulators hold the
+// transposed tile -- swaps the pool back to the loaded layout and finishes element-wise: 0.67 GB, no LDS round trip
+// of the activations, t and dx written with 16-byte stores.  Rounding points are the two-launch route's (t to bf16,
+// fp32 pool of bf16 operands, fp32 epilogue on the bf16 inputs); the pool sums each group of 16 channels in another
+// order, so dx agrees to fp32 / one-bf16-ulp rounding, not bitwise.
+#include "lic_common.h"
+
+typedef __bf16 gb_bf16;
+typedef __bf16 gb_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 gb_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float gb_f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned gb_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned gb_u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+
+struct GdnBwdHParams {
+  const gb_bf16* g;
+  const gb_bf16* x;
+  const gb_bf16* norm;
+  const gb_bf16* gamma;  // gamma_eff packed by lic_pack_weight_bf16_kperm(taps 1, K = C (norm index), N = C, s_k = C, s_n = 1)
+  gb_bf16* dx;
+  gb_bf16* t;
+  long P;
+  int inverse;
+};
+
+template <int NT4>  // C / 32
+__global__ __launch_bounds__(256, NT4 <= 2 ? 2 : 1) void gdn_bwd_bf16_kernel(const GdnBwdHParams p) {
+  constexpr int C = 32 * NT4, NG = C / 16;
+  __shared__ __attribute__((aligned(16))) gb_bf16 gam[C * C];  // [chunk = C/32][tile = C/32][2][64 lanes][8]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 31, lh = lane >> 5;
+  // gamma panel: C*C*2 bytes, 16 bytes per thread per pass
+#pragma unroll
+  for (int i = 0; i < C * C / 8 / 256; ++i)
+    reinterpret_cast<gb_u32x4*>(gam)[i * 256 + tid] = reinterpret_cast<const gb_u32x4*>(p.gamma)[i * 256 + tid];
+  __syncthreads();
+
+  const long ntile = (p.P + 127) / 128;
+  for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    const long row = tile * 128 + wave * 32 + li;
+    const bool rok = row < p.P;
+    const long off = (rok ? row : 0) * C + 8 * lh;
+    // ---- one sweep: 8 consecutive channels of group s for this lane's pixel, all three streams in flight at once
+    gb_u32x4 gq[NG], xq[NG], nq[NG];
+#pragma unroll
+    for (int s = 0; s < NG; ++s) {
+      gq[s] = *reinterpret_cast<const gb_u32x4*>(p.g + off + 16 * s);
+      xq[s] = *reinterpret_cast<const gb_u32x4*>(p.x + off + 16 * s);
+      nq[s] = *reinterpret_cast<const gb_u32x4*>(p.norm + off + 16 * s);
+    }
+    auto lo = [](unsigned u) { return __builtin_bit_cast(float, u << 16); };
+    auto hi = [](unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); };
+    auto pack2 = [](float a, float b) {
+      const gb_f32x2 v = {a, b};
+      return __builtin_bit_cast(unsigned, __builtin_convertvector(v, gb_bf16x2));
+    };
+    // ---- t = dL/dnorm, rounded to bf16 (what the d-gamma / d-beta launches read); its kperm B operand
+    gb_u32x4 tb[NG];
+#pragma unroll
+    for (int s = 0; s < NG; ++s) {
+      gb_u32x4 tq;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const float n0 = lo(nq[s][d]), n1 = hi(nq[s][d]);
+        const float r0 = __builtin_amdgcn_rsqf(n0), r1 = __builtin_amdgcn_rsqf(n1);
+        const float gx0 = lo(gq[s][d]) * lo(xq[s][d]), gx1 = hi(gq[s][d]) * hi(xq[s][d]);
+        const float t0 = p.inverse ? 0.5f * gx0 * r0 : -0.5f * gx0 * r0 * (r0 * r0);
+        const float t1 = p.inverse ? 0.5f * gx1 * r1 : -0.5f * gx1 * r1 * (r1 * r1);
+        tq[d] = pack2(t0, t1);
+      }
+      if (rok) *reinterpret_cast<gb_u32x4*>(p.t + off + 16 * s) = tq;
+      // lanes li / li + 32 hold channels 0..7 / 8..15 of the group; the kperm operand wants {0..3, 8..11} / {4..7, 12..15}
+      const gb_u32x2 a = __builtin_amdgcn_permlane32_swap(tq[0], tq[2], false, false);
+      const gb_u32x2 b = __builtin_amdgcn_permlane32_swap(tq[1], tq[3], false, false);
+      tb[s] = gb_u32x4{a[0], b[0], a[1], b[1]};
+    }
+    // ---- pool^T[co][pixel] = sum_ci gamma_eff[ci][co] t[pixel][ci]   (A = gamma from LDS, B = t from registers)
+    f32x16 acc[NT4];
+#pragma unroll
+    for (int bo = 0; bo < NT4; ++bo)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[bo][r] = 0.0f;
+#pragma unroll
+    for (int s = 0; s < NG; ++s) {
+      const gb_bf16x8 b2 = __builtin_bit_cast(gb_bf16x8, tb[s]);
+#pragma unroll
+      for (int bo = 0; bo < NT4; ++bo) {
+        const gb_bf16x8 a2 = *reinterpret_cast<const gb_bf16x8*>(gam + (((s >> 1) * NT4 + bo) * 2 + (s & 1)) * 512 + lane * 8);
+        acc[bo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[bo], 0, 0, 0);
+      }
+    }
+    // ---- dx = g f + 2 x pool, f = norm^-1/2 (IGDN: ^+1/2); the pool goes back to the loaded layout first:
+    // the accumulator of channel tile bo holds, for this lane's pixel, channels 8 gg + 4 lh + {0..3} (gg = 0..3);
+    // group s = 2 bo + (gg >> 1) wants channels 8 lh + {0..7}
+#pragma unroll
+    for (int s = 0; s < NG; ++s) {
+      const int bo = s >> 1, g0 = 2 * (s & 1);   // registers 4 g0 .. 4 g0 + 7 of acc[bo]
+      float pl[8];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // (by value first: __builtin_bit_cast on a vector-element lvalue reads element 0 of the vector with this clang)
+        const float q0 = acc[bo][4 * g0 + e], q1 = acc[bo][4 * g0 + 4 + e];
+        const gb_u32x2 sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, q0),
+                                                             __builtin_bit_cast(unsigned, q1), false, false);
+        // low lanes: (own first quad, partner's first quad) = channels e, 4 + e; high lanes: (partner's second quad,
+        // own second quad) = channels 8 + e, 12 + e
+        const unsigned w0 = sw[0], w1 = sw[1];
+        pl[e] = __builtin_bit_cast(float, w0);
+        pl[4 + e] = __builtin_bit_cast(float, w1);
+      }
+      gb_u32x4 dq;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const float n0 = lo(nq[s][d]), n1 = hi(nq[s][d]);
+        const float f0 = p.inverse ? __builtin_amdgcn_sqrtf(n0) : __builtin_amdgcn_rsqf(n0);
+        const float f1 = p.inverse ? __builtin_amdgcn_sqrtf(n1) : __builtin_amdgcn_rsqf(n1);
+        const float d0 = __builtin_fmaf(2.0f * lo(xq[s][d]), pl[2 * d], lo(gq[s][d]) * f0);
+        const float d1 = __builtin_fmaf(2.0f * hi(xq[s][d]), pl[2 * d + 1], hi(gq[s][d]) * f1);
+        dq[d] = pack2(d0, d1);
+      }
+      if (rok) *reinterpret_cast<gb_u32x4*>(p.dx + off + 16 * s) = dq;
+    }
+  }
+}
+
+}  // namespace
+
+LIC_EXPORT int lic_gdn_bwd_bf16_supported(int32_t C) { return C == 64 || C == 128; }
+
+// g, x, norm, dx, t: dense bf16 [P][C]; gamma_packed: lic_pack_weight_bf16_kperm(gamma_eff, taps 1, K = C, N = C,
+// s_k = C, s_n = 1)
+LIC_EXPORT int lic_gdn_bwd_bf16(const void* g, const void* x, const void* norm, const void* gamma_packed, void* dx,
+                                void* t, int64_t P, int32_t C, int32_t inverse, lic_stream_t stream) {
+  if (!g || !x || !norm || !gamma_packed || !dx || !t || P <= 0) return LIC_ERR_INVALID;
+  if (!lic_gdn_bwd_bf16_supported(C)) return LIC_ERR_UNSUPPORTED;
+  for (const void* q : {g, x, norm, gamma_packed, (const void*)dx, (const void*)t})
+    if (reinterpret_cast<uintptr_t>(q) & 15) return LIC_ERR_INVALID;
+  GdnBwdHParams p{(const gb_bf16*)g, (const gb_bf16*)x, (const gb_bf16*)norm, (const gb_bf16*)gamma_packed,
+                  (gb_bf16*)dx, (gb_bf16*)t, (long)P, inverse ? 1 : 0};
+  const long ntile = (P + 127) / 128;
+  const unsigned grid = (unsigned)(ntile < 2048 ? ntile : 2048);
+  if (C == 64) hipLaunchKernelGGL((gdn_bwd_bf16_kernel<2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((gdn_bwd_bf16_kernel<4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+  return lic_check_launch();
+}

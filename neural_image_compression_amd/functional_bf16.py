@@ -9,6 +9,7 @@ No CPU fallback, same rules as functional.py.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -418,17 +419,31 @@ def _gdn_backward_bf16(xh, norm, beta, gamma, g, inverse, beta_bound, gamma_boun
     B, H, W, Cc = xh.shape
     P = B * H * W
     t = torch.empty_like(xh)
-    L.check(lib.lic_gdn_dnorm_bf16(_ptr(g), _ptr(xh), _ptr(norm), _ptr(t), xh.numel(), int(inverse), _stream()),
-            "lic_gdn_dnorm_bf16")
     dxh = dbeta = dgamma = None
-    if need_dx:
+    if need_dx and lib.lic_gdn_bwd_bf16_supported(Cc) and os.environ.get("LIC_BF16_GDN_BWD", "1") != "0":
+        # one sweep: g, x, norm read once, t and dx written (lic_gdn_bf16.hip); the two-launch route below moves
+        # 1.8x the bytes
         dxh = torch.empty_like(xh)
-        gp = prepared(gamma, "bf16.gdn_g")
+        gp = prepared(gamma, "bf16.gdn_gp")
         if gp is None:
-            gp = _pack_bf16(_gamma_eff(gamma, gamma_bound, pedestal), 1, Cc, Cc, 0, Cc, 1)
-        _igemm_bf16(t, gp, dxh, B=1, Hi=1, Wi=P, Cin=Cc, Ho=1, Wo=P, Cout=Cc,
-                    kh=1, kw=1, stride=1, pad=0, transposed=False,
-                    epilogue=L.EPI_IGDN_BWD if inverse else L.EPI_GDN_BWD, aux=g, aux2=xh, aux3=norm)
+            gp = _pack_bf16(_gamma_eff(gamma, gamma_bound, pedestal), 1, Cc, Cc, 0, Cc, 1, kperm=True)
+        from . import functional as F_
+        if F_.KERNEL_TRACE is not None:
+            F_.KERNEL_TRACE.add(f"gdn_bwd_bf16_kernel<{Cc // 32}>")
+        F_._timed(f"gdn_bwd_bf16_kernel<{Cc // 32}>", 2 * P * Cc * Cc, 10 * P * Cc,
+                  lambda: L.check(lib.lic_gdn_bwd_bf16(_ptr(g), _ptr(xh), _ptr(norm), _ptr(gp), _ptr(dxh), _ptr(t), P, Cc,
+                                                       int(inverse), _stream()), "lic_gdn_bwd_bf16"))
+    else:
+        L.check(lib.lic_gdn_dnorm_bf16(_ptr(g), _ptr(xh), _ptr(norm), _ptr(t), xh.numel(), int(inverse), _stream()),
+                "lic_gdn_dnorm_bf16")
+        if need_dx:
+            dxh = torch.empty_like(xh)
+            gp = prepared(gamma, "bf16.gdn_g")
+            if gp is None:
+                gp = _pack_bf16(_gamma_eff(gamma, gamma_bound, pedestal), 1, Cc, Cc, 0, Cc, 1)
+            _igemm_bf16(t, gp, dxh, B=1, Hi=1, Wi=P, Cin=Cc, Ho=1, Wo=P, Cout=Cc,
+                        kh=1, kw=1, stride=1, pad=0, transposed=False,
+                        epilogue=L.EPI_IGDN_BWD if inverse else L.EPI_GDN_BWD, aux=g, aux2=xh, aux3=norm)
     dbe = dge = db_conv = None
     if bias_from_dx and need_dbeta and dxh is not None:
         dbe, db_conv = _colsum2_bf16(t, dxh, P, Cc)

@@ -107,6 +107,8 @@ class StepPrep:
                 if half:   # the same operand in the K order of the one-launch conv+GDN kernel
                     pack(m.gamma, "gdn_gTp", True, kperm=True, s_k=1, s_n=Cc, **gkw)
                 pack(m.gamma, "gdn_g", half, s_k=Cc, s_n=1, **gkw)      # backward: t . gamma_eff
+                if half:   # ... in the K order of the one-sweep backward kernel (lic_gdn_bwd_bf16)
+                    pack(m.gamma, "gdn_gp", True, kperm=True, s_k=Cc, s_n=1, **gkw)
                 params += [m.beta, m.gamma]
             elif isinstance(m, (Conv2d, ConvTranspose2d)):
                 w = m.weight

@@ -437,6 +437,52 @@ def test_gdn_bf16(env, inverse):
     scale_close(host(m.gamma.grad), O.gdn_reparam_bwd(gamma_p, dge, 0.0), 3e-2, "dgamma")
 
 
+# the one-sweep GDN / IGDN backward (lic_gdn_bwd_bf16: t and dx from one read of g, x, norm) against the oracle on
+# small ragged cases and against the two-launch route (lic_gdn_dnorm_bf16 + the GDN_BWD epilogue of lic_igemm_bf16)
+# up to more tiles than the persistent grid has workgroups.  t is bitwise the two-launch route's; dx sums each group
+# of 16 channels in another order: fp32 rounding of the pool, at most the odd bf16 flip of the stored result
+@pytest.mark.parametrize("C,P,inverse", [(64, 1, False), (64, 37, True), (128, 131, False), (128, 1000, True),
+                                         (64, 128 * 2048 + 77, False), (128, 128 * 700 + 5, True)])
+def test_gdn_bwd_one_sweep_bf16(env, C, P, inverse):
+    nic, FB, O, d = env
+    from neural_image_compression_amd import _lib as L
+    from neural_image_compression_amd.functional import _ptr, _stream
+    lib = L.load()
+    assert lib.lic_gdn_bwd_bf16_supported(C) == 1 and lib.lic_gdn_bwd_bf16_supported(192) == 0
+    r = np.random.RandomState(C + P)
+    gen = torch.Generator(device="cpu").manual_seed(C + P)
+    x = torch.randn(P, C, generator=gen).to(BF).to(d)
+    g = torch.randn(P, C, generator=gen).to(BF).to(d)
+    nrm = (torch.rand(P, C, generator=gen) * 3.0 + 0.25).to(BF).to(d)
+    gamma_e = torch.from_numpy(rb(np.abs(r.randn(C, C)).astype(np.float32) * 0.05)).to(d)   # [norm index][x index]
+    gp1 = FB._pack_bf16(gamma_e, 1, C, C, 0, C, 1, kperm=True)
+    dx1, t1 = torch.empty_like(x), torch.empty_like(x)
+    L.check(lib.lic_gdn_bwd_bf16(_ptr(g), _ptr(x), _ptr(nrm), _ptr(gp1), _ptr(dx1), _ptr(t1), P, C, int(inverse),
+                                 _stream()), "lic_gdn_bwd_bf16")
+    # two-launch route
+    t2, dx2 = torch.empty_like(x), torch.empty_like(x)
+    L.check(lib.lic_gdn_dnorm_bf16(_ptr(g), _ptr(x), _ptr(nrm), _ptr(t2), x.numel(), int(inverse), _stream()), "dnorm")
+    gp2 = FB._pack_bf16(gamma_e, 1, C, C, 0, C, 1)
+    FB._igemm_bf16(t2, gp2, dx2, B=1, Hi=1, Wi=P, Cin=C, Ho=1, Wo=P, Cout=C, kh=1, kw=1, stride=1, pad=0,
+                   transposed=False, epilogue=L.EPI_IGDN_BWD if inverse else L.EPI_GDN_BWD, aux=g, aux2=x, aux3=nrm)
+    torch.cuda.synchronize()
+    assert torch.equal(t1, t2), "t differs from lic_gdn_dnorm_bf16"
+    a, b = dx1.float(), dx2.float()
+    scale = float(b.abs().max())
+    assert float((a - b).abs().max()) <= 2.0 ** -7 * scale, (float((a - b).abs().max()), scale)
+    assert float((a != b).float().mean()) < 0.02     # the odd last-bit flip, no more
+    if P <= 1000:
+        # the oracle on the same bf16 inputs (x as [1, C, P, 1] NCHW)
+        xn = x.float().cpu().numpy().T.reshape(1, C, P, 1)
+        gn = g.float().cpu().numpy().T.reshape(1, C, P, 1)
+        nn = nrm.float().cpu().numpy().T.reshape(1, C, P, 1)
+        dxo = O.gdn_bwd(xn, nn, gamma_e.cpu().numpy(), gn, inverse)[0]
+        scale_close(a.cpu().numpy().T.reshape(1, C, P, 1), dxo, 2e-2, "one-sweep dx against the oracle")
+    # unsupported widths and misaligned pointers are refused, not mis-run
+    assert lib.lic_gdn_bwd_bf16(_ptr(g), _ptr(x), _ptr(nrm), _ptr(gp1), _ptr(dx1), _ptr(t1), P, 192, 0, _stream()) \
+        == -2   # LIC_ERR_UNSUPPORTED
+
+
 # conv -> GDN in one launch (LIC_EPI_CONV_GDN of lic_igemm_bf16): every N tile, ragged M, the 4-phase transposed
 # gather and the RGB stem, against the two-launch path.  Same rounding points (x and x^2 to bf16, fp32 norm); the
 # fused pool sums each group of 16 channels in another order, so: y within one bf16 rounding, gradients (which see
