@@ -137,6 +137,9 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="2", choices=sorted(CONFIGS))
+    ap.add_argument("--plan", default="auto", choices=("auto", "on", "off"),
+                    help="replay the step from a launch plan (plan.StepPlan: the captured step issued on two streams by "
+                         "liblic_hip.so, no Python between launches); auto = on for the host-paced bf16 configs on one GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile-events", action="store_true")
     ap.add_argument("--no-analysis-fwd", action="store_true",
@@ -213,11 +216,31 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The bf16 configurations are host-paced (~3 ms of Python around 0.7 ms of launches and ~3 ms of GPU work per
+    # step): their step is captured once and replayed by the library's launch plan -- the same kernels, operands and
+    # two streams, bit-identical losses (tests/test_gpu_plan.py) -- with the optimizer's one launch behind it.
+    # The fp32 configurations are GPU-bound; data-parallel runs need autograd's hooks for the gradient exchange.
+    use_plan = args.plan == "on" or (args.plan == "auto" and bf16)
+    if use_plan and (world > 1 or reducer is not None):
+        if args.plan == "on":
+            raise SystemExit("--plan on: a launch plan replays one GPU's step (the gradient all-reduce runs from autograd hooks)")
+        use_plan = False
+    eager_step = step
+    plan = None
+    if use_plan:
+        from neural_image_compression_amd.plan import StepPlan
+        plan = StepPlan(model, nic.rd_loss, lam, x)
+
+        def step():
+            _, res = plan.step(x)
+            opt.step()
+            return res
+
     for _ in range(args.warmup):
         step()
     fence()
     prof = None
-    if not args.no_profile_events:
+    if not args.no_profile_events and plan is None:
         # bracket only the launches that can be the dominant kernel (>= 2 GFLOP): ~60 event pairs per step
         # instead of ~400, so the profile costs the step < 0.3 %
         F_.PROFILE_MIN_FLOP = 2e9
@@ -240,8 +263,21 @@ def main():
             stride = max(1, -(-(args.steps * per_step) // MAX_LIVE_PAIRS))
     fence()
     el = time.perf_counter() - t0
+    final_res = {k: (v.detach().clone() if torch.is_tensor(v) else v) for k, v in res.items()}
+    if plan is not None and not args.no_profile_events:
+        # a replay runs no Python between launches, so there is nothing to record events from: the per-kernel
+        # brackets come from eager steps of the same model right AFTER the timed region (same kernels and launch
+        # geometry; not part of `value`)
+        F_.PROFILE_MIN_FLOP = 2e9
+        prof = []
+        for _ in range(min(4, args.steps)):
+            F_.PROFILE = prof
+            eager_step()
+            bracketed_steps += 1
+        torch.cuda.synchronize()
     F_.PROFILE = None
     F_.PROFILE_MIN_FLOP = 0.0
+    res = final_res
     t = torch.tensor([el], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -271,7 +307,10 @@ def main():
                                    f"fwd+rd_loss(lambda={lam})+bwd+Adam, {B}x3x{H}x{W} per GPU, "
                                    + ("bf16 storage / fp32 accumulate in the conv+GDN stacks, fp32 elsewhere" if bf16 else "fp32"),
                        "global_batch": world * B, "parallelism": f"dp{world}",
-                       "loss": round(float(res["loss"].detach()), 6)},
+                       "loss": round(float(res["loss"].detach()), 6),
+                       "step": "launch plan: the captured step replayed on two HIP streams by lic_plan_replay + FusedAdam "
+                               f"({plan.info['kernels']} kernel nodes, {plan.info['on_side_stream']} on the second stream, "
+                               f"{plan.info['events']} cross-stream events)" if plan is not None else "eager (autograd)"},
         }
         if prof:
             # per-kernel totals from HIP events recorded around every MFMA launch of the timed region
@@ -314,6 +353,8 @@ def main():
                 "traffic_source": traffic_src,
                 "launches": n, "avg_launch_ms": round(secs / n * 1e3, 4),
                 "steps_bracketed": bracketed_steps,
+                "bracketed": "eager steps right after the timed region (a plan replay has no Python between launches "
+                             "to record events from)" if plan is not None else "sampled steps of the timed region",
                 "alg_gflop_per_launch": round(flops / n / 1e9, 3),
                 "hbm_frac_of_alg_bytes": round(abytes / secs / 1e9 / HBM_PEAK_GBS, 4),
             }

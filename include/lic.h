@@ -472,6 +472,28 @@ int lic_adam_run(const lic_adam_job* jobs_device, int32_t njobs, int64_t total_b
                  double lr, double beta1, double beta2, double eps, double weight_decay, double bias_correction1,
                  double bias_correction2, lic_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * lic_plan -- one training step (Trainer.py:75-90: forward, loss, backward) replayed on TWO HIP streams without
+ *   Python in the loop.  The step is captured ONCE as a HIP graph (torch.cuda.graph with keep_graph=True: torch's
+ *   private pool keeps every pointer fixed); lic_plan_create reads the graph's kernel / memset / memcpy / empty nodes
+ *   and its edges back, orders them topologically in capture order, spreads them over two streams and keeps one
+ *   event record + wait per remaining cross-stream edge; lic_plan_replay issues them with plain stream launches
+ *   (this ROCm walks a multi-branch graph node by node from the host: 8 ms per step instead of 0.1 ms, and a
+ *   single-branch graph gives up the decoder / latent-side and data-gradient / weight-gradient overlap).
+ *   `hip_graph` is a hipGraph_t and must outlive the plan (kernel arguments stay in the graph's storage).
+ *   lic_plan_replay(plan, main, side): work queued on `main` before the call precedes the plan, work queued on it
+ *   afterwards follows ALL of the plan; `side` is a second, otherwise idle stream of the same device (NULL or == main:
+ *   one stream).  info[0..5] = nodes, kernels, memsets, memcpys, nodes on `side`, cross-stream events.
+ *   Errors: LIC_ERR_UNSUPPORTED for a node kind that cannot be replayed (host, event, child-graph, allocation nodes;
+ *   copy nodes whose parameters this ROCm does not hand back); lic_plan_last_error() names it.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct lic_plan lic_plan;
+int lic_plan_create(void* hip_graph, lic_plan** out);
+int lic_plan_info(const lic_plan* plan, int64_t* info);
+int lic_plan_replay(lic_plan* plan, lic_stream_t main, lic_stream_t side);
+void lic_plan_destroy(lic_plan* plan);
+const char* lic_plan_last_error(void);
+
 int lic_version(void);        /* LIC_ABI_VERSION */
 int lic_last_hip_error(void); /* hipError_t of the most recent failed launch on this thread */
 const char* lic_arch(void);   /* "gfx950" */

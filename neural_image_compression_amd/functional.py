@@ -1081,14 +1081,19 @@ class _RdLossFn(torch.autograd.Function):
                                     _stream()), "lic_rd_loss_fwd")
         ctx.save_for_backward(xh, xx)
         ctx.cfg = (tuple(ly.shape), tuple(lz.shape), lambda_rd, num_pixels)
-        return out
+        # the loss as a tensor of its own on element 0 of the buffer: a `buf[0]` in the caller would make every
+        # backward start with select_backward's zero-fill and a 4-byte device copy (a memcpy node, which a launch
+        # plan -- plan.StepPlan -- cannot read back from the captured graph)
+        loss = out.new_empty(()).set_(out.untyped_storage(), out.storage_offset(), ())
+        ctx.mark_non_differentiable(out)
+        return out, loss
 
     @staticmethod
-    def backward(ctx, gout):
+    def backward(ctx, _gbuf, gloss):
         xh, xx = ctx.saved_tensors
         shy, shz, lam, num_pixels = ctx.cfg
         B = xx.shape[0]
-        gl = gout[0:1].contiguous()  # only `loss` carries gradient
+        gl = gloss.reshape(1).contiguous()  # only `loss` carries gradient
         dly = torch.empty(shy, device=xx.device, dtype=torch.float32)
         dlz = torch.empty(shz, device=xx.device, dtype=torch.float32)
         dxh = torch.empty_like(xh)
@@ -1099,6 +1104,7 @@ class _RdLossFn(torch.autograd.Function):
 
 
 def rd_loss_buffer(logp_y, logp_z, x_hat, x, lambda_rd):
+    """(result buffer [16 + 2B] -- no gradient --, loss: 0-d tensor on its element 0, differentiable)"""
     return _RdLossFn.apply(logp_y, logp_z, x_hat, x, float(lambda_rd))
 
 

@@ -12,9 +12,9 @@ _KEYS = ("loss", "bpp_y", "bpp_z", "bpp_total", "mse", "psnr", "bits_y", "bits_z
 def rd_loss(model_out: dict, x: torch.Tensor, lambda_rd: float, sync: bool = True):
     """sync=False returns 0-d device tensors instead of Python floats (no host sync at all)."""
     B = x.size(0)
-    buf = F_.rd_loss_buffer(model_out['logp_y'], model_out['logp_z'], model_out['x_hat'], x, lambda_rd)
+    buf, loss = F_.rd_loss_buffer(model_out['logp_y'], model_out['logp_z'], model_out['x_hat'], x, lambda_rd)
     det = buf.detach()
-    res = {'loss': buf[0]}
+    res = {'loss': loss}
     if sync:
         host = det[:9].tolist()
         for i, k in enumerate(_KEYS[1:], start=1):
@@ -36,10 +36,10 @@ def vision_rd_loss(model_out: dict, x: torch.Tensor, lambda_rd: float, gamma: fl
     import math
     B = x.size(0)
     num_pixels = x.size(2) * x.size(3)
-    buf = F_.rd_loss_buffer(model_out['logp_y1'], model_out['logp_z'], model_out['x_hat'], x, lambda_rd / 255.0 ** 2)
+    buf, loss0 = F_.rd_loss_buffer(model_out['logp_y1'], model_out['logp_z'], model_out['x_hat'], x, lambda_rd / 255.0 ** 2)
     bits_y2_img = -model_out['logp_y2'].sum(dim=(1, 2, 3)) / math.log(2.0)
     bpp_y2 = (bits_y2_img / num_pixels).mean()
-    loss = buf[0] + bpp_y2
+    loss = loss0 + bpp_y2
     det = buf.detach()
     rec_mse_img, psnr_img = det[16:16 + B], det[16 + B:16 + 2 * B]
     vis = vis_img = None

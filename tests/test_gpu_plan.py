@@ -1,0 +1,126 @@
+"""Launch plans (include/lic.h lic_plan_*, plan.StepPlan): a captured step replayed on two streams by the library must
+do exactly what the eager step does -- same kernels, same operands, hence the same bits -- and the generic executor
+must honour every dependency of a captured fork / join."""
+import ctypes as C
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("needs an MI355X")
+
+
+def test_plan_replays_a_fork_join_capture():
+    """a diamond captured from two streams (main: a, c, d; side: b), replayed through lic_plan_replay on two other
+    streams after the input changed: the result is what the dependencies demand"""
+    _need_gpu()
+    from neural_image_compression_amd import _lib as L
+    lib = L.load()
+    dev = torch.device("cuda:0")
+    x = torch.arange(1 << 20, device=dev, dtype=torch.float32)
+    side_cap = torch.cuda.Stream()
+    g = torch.cuda.CUDAGraph(keep_graph=True)
+    with torch.cuda.graph(g):
+        main = torch.cuda.current_stream()
+        a = x * 2.0
+        for _ in range(20):              # long enough that a missing wait would read a stale `a`
+            a = a * 1.0001 + 1.0
+        side_cap.wait_stream(main)
+        with torch.cuda.stream(side_cap):
+            b = a + 1.0
+            for _ in range(10):
+                b = b * 0.5 + 3.0
+        c = a * 3.0
+        z = torch.zeros_like(c)          # (a fill: kernel or memset node)
+        c = c + z
+        main.wait_stream(side_cap)
+        e = b + c
+
+    def expect(xv):
+        a = xv * 2.0
+        for _ in range(20):
+            a = a * 1.0001 + 1.0
+        b = a + 1.0
+        for _ in range(10):
+            b = b * 0.5 + 3.0
+        return b + a * 3.0
+
+    plan = C.c_void_p()
+    L.check(lib.lic_plan_create(C.c_void_p(g.raw_cuda_graph()), C.byref(plan)), "lic_plan_create")
+    info = (C.c_int64 * 6)()
+    L.check(lib.lic_plan_info(plan, info), "lic_plan_info")
+    nodes, kernels, memsets, memcpys, on_side, events = list(info)
+    assert nodes == kernels + memsets + memcpys and memcpys == 0 and on_side >= 3 and events >= 2, list(info)
+    s_main, s_side = torch.cuda.Stream(), torch.cuda.Stream()
+    for trial in range(3):
+        x.copy_(torch.arange(1 << 20, device=dev, dtype=torch.float32) * (trial + 1.5))
+        torch.cuda.synchronize()
+        with torch.cuda.stream(s_main):
+            L.check(lib.lic_plan_replay(plan, C.c_void_p(s_main.cuda_stream), C.c_void_p(s_side.cuda_stream)), "replay")
+            got = e.clone()              # queued on `main` after the call: ordered after ALL of the plan
+        torch.cuda.synchronize()
+        assert torch.equal(got, expect(x)), trial
+    # one stream: the same plan, serialised
+    x.mul_(0.25)
+    torch.cuda.synchronize()
+    L.check(lib.lic_plan_replay(plan, C.c_void_p(s_main.cuda_stream), None), "replay")
+    torch.cuda.synchronize()
+    assert torch.equal(e, expect(x))
+    lib.lic_plan_destroy(plan)
+    assert lib.lic_plan_create(None, C.byref(plan)) == -1     # LIC_ERR_INVALID
+
+
+@pytest.mark.parametrize("precision,M,K", [("bf16", 128, 3), ("fp32", 64, 1)])
+def test_step_plan_equals_eager_training(precision, M, K):
+    """five optimizer steps from the same seed, eager and planned: every loss and every parameter bit for bit"""
+    _need_gpu()
+    import neural_image_compression_amd as nic
+    from neural_image_compression_amd.plan import StepPlan
+    dev = torch.device("cuda:0")
+    B, H, W, lam = 4, 128, 128, 0.01
+    g = torch.Generator(device="cpu").manual_seed(11)
+    xs = [torch.rand(B, 3, H, W, generator=g).to(dev).contiguous(memory_format=torch.channels_last) for _ in range(2)]
+
+    def build():
+        torch.manual_seed(3)
+        m = nic.JointAutoregressiveHierarchical(M, K).to(dev)
+        if precision == "bf16":
+            m.set_precision("bf16")
+        return m, nic.FusedAdam(m.parameters(), lr=1e-3)
+
+    ma, oa = build()
+    torch.cuda.manual_seed(5)
+    losses_a = []
+    for i in range(5):
+        oa.zero_grad(set_to_none=True)
+        res = nic.rd_loss(ma(xs[i % 2]), xs[i % 2], lam, sync=False)
+        res["loss"].backward()
+        oa.step()
+        losses_a.append(float(res["loss"].detach()))
+
+    mb, ob = build()
+    plan = StepPlan(mb, nic.rd_loss, lam, xs[0])
+    assert plan.info["kernels"] > 100 and plan.info["on_side_stream"] > 10 and plan.info["events"] >= 2, plan.info
+    torch.cuda.manual_seed(5)
+    losses_b = []
+    for i in range(5):
+        if i == 2:
+            ob.zero_grad(set_to_none=True)   # (a caller that clears gradients between steps: the plan restores them)
+        out, res = plan.step(xs[i % 2])
+        ob.step()
+        losses_b.append(float(res["loss"].detach()))
+    assert losses_a == losses_b, (losses_a, losses_b)
+    for (n, pa), pb in zip(ma.named_parameters(), mb.parameters()):
+        assert torch.equal(pa.detach(), pb.detach()), n
+    assert out["x_hat"].shape == (B, 3, H, W) and bool(torch.isfinite(out["x_hat"]).all())
+    with pytest.raises(Exception, match="captured for batches"):
+        plan.step(xs[0][:2])
+    # the model is still usable eagerly, on the weights the planned steps trained
+    with torch.no_grad():
+        ea, eb = ma(xs[0], training=False)["x_hat"], mb(xs[0], training=False)["x_hat"]
+    assert torch.equal(ea, eb)
+    plan.close()

@@ -40,6 +40,9 @@ def main():
     for _ in range(3):
         step()
     torch.cuda.synchronize()
+    if os.environ.get("LIC_PROFILE_BACKWARD", "1") == "1":
+        # autograd runs CUDA backward nodes on its own thread, which cProfile does not see: keep them on this one
+        torch.autograd.set_multithreading_enabled(False)
     pr = cProfile.Profile()
     pr.enable()
     for _ in range(steps):
@@ -47,7 +50,8 @@ def main():
     pr.disable()
     torch.cuda.synchronize()
     st = pstats.Stats(pr)
-    st.sort_stats("tottime").print_stats(45)
+    st.sort_stats("tottime").print_stats(70)
+    st.sort_stats("cumulative").print_stats(60)
 
 
 if __name__ == "__main__":
