@@ -473,24 +473,57 @@ int lic_adam_run(const lic_adam_job* jobs_device, int32_t njobs, int64_t total_b
                  double bias_correction2, lic_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
- * lic_plan -- one training step (Trainer.py:75-90: forward, loss, backward) replayed on TWO HIP streams without
- *   Python in the loop.  The step is captured ONCE as a HIP graph (torch.cuda.graph with keep_graph=True: torch's
- *   private pool keeps every pointer fixed); lic_plan_create reads the graph's kernel / memset / memcpy / empty nodes
- *   and its edges back, orders them topologically in capture order, spreads them over two streams and keeps one
- *   event record + wait per remaining cross-stream edge; lic_plan_replay issues them with plain stream launches
- *   (this ROCm walks a multi-branch graph node by node from the host: 8 ms per step instead of 0.1 ms, and a
- *   single-branch graph gives up the decoder / latent-side and data-gradient / weight-gradient overlap).
+ * RGB head in bf16 storage without column matrices (Components.py:45: ConvTranspose2d(C, 3, 5, stride 2, padding 2,
+ *   output_padding 1); the column-matrix route of lic_igemm_bf16 + lic_col2im_bf16 / lic_im2col_bf16 remains for
+ *   other geometries).
+ *   lic_head_convt_bf16: out fp32 [B][2 Hi][2 Wi][3] = conv_transpose2d(x bf16 [B][Hi][Wi][Cin]) + bias; `w_packed` =
+ *     lic_pack_weight_bf16(taps 1, K = Cin, N = 75..80) of the matrix w[ci][3 * (5 ky + kx) + colour] (the forward
+ *     operand of the column-matrix route); Cin in {64, 128, 192}.  fp32 accumulation, nothing rounded between the
+ *     channel contraction and the tap sum.
+ *   lic_stem_conv_bf16: y bf16 [B][ceil(H/2)][ceil(W/2)][Cout] = conv2d(x fp32 [B][H][W][3], w, stride 2, padding 2)
+ *     + bias, `w_packed` = lic_pack_stem_weight_bf16 of a [Cout][3][5][5] tensor -- the convolution of
+ *     lic_stem_gdn_bf16 without the GDN.  The data gradient of the head is this convolution of dL/d(image) with the
+ *     head's own weight tensor (ConvTranspose2d stores it as [Cin][3][5][5]).
+ * ------------------------------------------------------------------------------------------ */
+int lic_head_convt_bf16_supported(int32_t Cin, int32_t Cout, int32_t kh, int32_t kw, int32_t stride, int32_t pad,
+                                  int32_t out_pad);
+int lic_head_convt_bf16(const void* x, const void* w_packed, const float* bias, float* out, int32_t B, int32_t Hi,
+                        int32_t Wi, int32_t Cin, lic_stream_t stream);
+int lic_stem_conv_bf16(const float* x, const void* w_packed, const float* bias, void* y, int32_t B, int32_t H, int32_t W,
+                       int32_t Cout, lic_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * lic_plan -- one training step (Trainer.py:75-90: forward, loss, backward) replayed on up to THREE HIP streams
+ *   without Python in the loop.  The step is captured ONCE as a HIP graph (torch.cuda.graph with keep_graph=True:
+ *   torch's private pool keeps every pointer fixed); lic_plan_create reads the graph's kernel / memset / memcpy /
+ *   empty nodes and its edges back into a list of operations, and a SCHEDULE puts them in an issue order, each on one
+ *   of the streams, with one event record + wait per cross-stream edge that stream order does not already imply;
+ *   lic_plan_replay issues the schedule with plain stream launches (this ROCm walks a multi-branch graph node by node
+ *   from the host: 8 ms per step instead of 0.1 ms, and a single-branch graph gives up the decoder / latent-side and
+ *   data-gradient / weight-gradient overlap).  Every schedule honours every edge of the capture, so a replay computes
+ *   what the captured step computed, bit for bit.
  *   `hip_graph` is a hipGraph_t and must outlive the plan (kernel arguments stay in the graph's storage).
- *   lic_plan_replay(plan, main, side): work queued on `main` before the call precedes the plan, work queued on it
- *   afterwards follows ALL of the plan; `side` is a second, otherwise idle stream of the same device (NULL or == main:
- *   one stream).  info[0..5] = nodes, kernels, memsets, memcpys, nodes on `side`, cross-stream events.
+ *   lic_plan_replay(plan, main, sides, n_sides): work queued on `main` before the call precedes the plan, work queued
+ *   on it afterwards follows ALL of the plan; `sides` = up to two more, otherwise idle streams of the same device
+ *   (fewer than the schedule uses: the missing ones fold onto the last one given; n_sides = 0: one stream).
+ *   info[0..6] = operations, kernels, memsets, memcpys, operations not on `main`, cross-stream events, 1 when a
+ *   tuned schedule is in use.
+ *   lic_plan_create's schedule is the capture's own: the capture's streams are chains of the graph, and where a chain
+ *   forks the successor with the longest way to go stays on the stream.  lic_plan_tune(plan, main, sides, n_sides,
+ *   result) times every operation (one-stream replays with an event between operations), list-schedules them
+ *   (earliest possible start first, the more critical operation on ties; long kernels of >= 192 workgroups take turns),
+ *   measures capture order and three candidates end to end and keeps a tuned one only if it is >= 2 % faster;
+ *   result[0..3] = sum of operation times, capture-order step, best tuned step (all us), 1 if kept.  It replays the
+ *   plan a few dozen times: the capture must be idempotent (no in-place update of its own inputs -- keep the
+ *   optimizer outside).
  *   Errors: LIC_ERR_UNSUPPORTED for a node kind that cannot be replayed (host, event, child-graph, allocation nodes;
- *   copy nodes whose parameters this ROCm does not hand back); lic_plan_last_error() names it.
+ *   1-D copy nodes, whose parameters this ROCm does not hand back); lic_plan_last_error() names it.
  * ------------------------------------------------------------------------------------------ */
 typedef struct lic_plan lic_plan;
 int lic_plan_create(void* hip_graph, lic_plan** out);
 int lic_plan_info(const lic_plan* plan, int64_t* info);
-int lic_plan_replay(lic_plan* plan, lic_stream_t main, lic_stream_t side);
+int lic_plan_replay(lic_plan* plan, lic_stream_t main, const lic_stream_t* sides, int32_t n_sides);
+int lic_plan_tune(lic_plan* plan, lic_stream_t main, const lic_stream_t* sides, int32_t n_sides, double* result);
 void lic_plan_destroy(lic_plan* plan);
 const char* lic_plan_last_error(void);
 

@@ -137,9 +137,13 @@ SIGNATURES = {
     "lic_prep_run": (C.c_int, [_vp, _i32, _i64, _vp]),
     "lic_adam_plan": (_i64, [C.POINTER(AdamJob), _i32]),
     "lic_adam_run": (C.c_int, [_vp, _i32, _i64, _vp] + [C.c_double] * 7 + [_vp]),
+    "lic_head_convt_bf16_supported": (C.c_int, [_i32] * 7),
+    "lic_head_convt_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "lic_stem_conv_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "lic_plan_create": (C.c_int, [_vp, C.POINTER(C.c_void_p)]),
     "lic_plan_info": (C.c_int, [_vp, C.POINTER(C.c_int64)]),
-    "lic_plan_replay": (C.c_int, [_vp, _vp, _vp]),
+    "lic_plan_replay": (C.c_int, [_vp, _vp, C.POINTER(C.c_void_p), _i32]),
+    "lic_plan_tune": (C.c_int, [_vp, _vp, C.POINTER(C.c_void_p), _i32, C.POINTER(C.c_double)]),
     "lic_plan_destroy": (None, [_vp]),
     "lic_plan_last_error": (C.c_char_p, []),
     "lic_version": (C.c_int, []),

@@ -52,11 +52,14 @@ __device__ __forceinline__ unsigned pack2(f32x2 v) {
 // (C = 128 compiles to 184 VGPR + 64 AGPR: two waves per SIMD.  Forced to three -- 168 registers, 60 bytes of
 // scratch -- it ran 100 us instead of 72 at config 3.  Issuing the NEXT tile's window loads under the current
 // tile's epilogue keeps 40 more registers live: one wave per SIMD, 94 us.  Neither kept.)
-template <int TW, int NW>
+// PLAIN: the convolution only (+ bias), written to p.y -- the data gradient of the RGB head (Components.py:45: the
+// gradient of ConvTranspose2d(C, 3, 5, 2, 2, 1) w.r.t. its input IS this convolution of the image gradient with the same
+// [C][3][5][5] weight), which ran as im2col + GEMM before.
+template <int TW, int NW, bool PLAIN = false>
 __global__ __launch_bounds__(64 * NW) void stem_gdn_bf16_kernel(const StemParams p) {
   constexpr int C = 32 * TW;
   constexpr int WEL = 5 * TW * 512;   // weight elements kept in LDS: k steps 0..4 of [step][tile][lane][8]
-  constexpr int GEL = TW * TW * 1024;  // gamma elements [t][tile][2][lane][8]
+  constexpr int GEL = PLAIN ? 8 : TW * TW * 1024;  // gamma elements [t][tile][2][lane][8]
   __shared__ __attribute__((aligned(16))) bf16_t s_w[WEL];
   __shared__ __attribute__((aligned(16))) bf16_t s_g[GEL];
   __shared__ __attribute__((aligned(16))) float s_bias[C];
@@ -69,11 +72,12 @@ __global__ __launch_bounds__(64 * NW) void stem_gdn_bf16_kernel(const StemParams
     *reinterpret_cast<bf16x8*>(s_w + i) =
         *reinterpret_cast<const bf16x8*>(p.w + ((long)((r >> 1) * TW + tile) * 2 + (r & 1)) * 512 + o);
   }
-  for (int i = tid * 8; i < GEL; i += 64 * NW * 8)
-    *reinterpret_cast<bf16x8*>(s_g + i) = *reinterpret_cast<const bf16x8*>(p.gamma + i);
+  if (!PLAIN)
+    for (int i = tid * 8; i < GEL; i += 64 * NW * 8)
+      *reinterpret_cast<bf16x8*>(s_g + i) = *reinterpret_cast<const bf16x8*>(p.gamma + i);
   for (int i = tid; i < C; i += 64 * NW) {
     s_bias[i] = p.bias ? p.bias[i] : 0.0f;
-    s_beta[i] = p.beta[i];
+    s_beta[i] = PLAIN ? 0.0f : p.beta[i];
   }
   __syncthreads();
 
@@ -162,8 +166,10 @@ __global__ __launch_bounds__(64 * NW) void stem_gdn_bf16_kernel(const StemParams
           sqpk[t][2 * g + h] = pack2(xb * xb);
         }
       }
-      if (p.conv_out) store_tile(p.conv_out, xpk, t);
+      if (PLAIN) store_tile(p.y, xpk, t);
+      else if (p.conv_out) store_tile(p.conv_out, xpk, t);
     }
+    if (PLAIN) continue;
     asm volatile("" ::: "memory");
     // per output-channel tile: norm^T = gamma_eff . (x^2)^T + beta, y = x * norm^-1/2 (or ^1/2)
     auto finish = [&](auto inv) {
@@ -242,6 +248,50 @@ LIC_EXPORT int lic_pack_stem_weight_bf16(const float* w, void* dst, int32_t Cout
   const int Npad = ((Cout + 63) / 64) * 64;
   hipLaunchKernelGGL(pack_stem_weight_bf16_kernel, dim3(ew_grid(3L * Npad * 32, 256)), dim3(256), 0,
                      (hipStream_t)stream, w, (bf16_t*)dst, Cout, Npad);
+  return lic_check_launch();
+}
+
+// The convolution alone: y[B][ceil(H/2)][ceil(W/2)][Cout] (bf16) = conv2d(x fp32 [B][H][W][3], w, stride 2, padding 2)
+// + bias.  Used as the data gradient of the RGB head: x = dL/d(image), w = the ConvTranspose2d weight [Cout][3][5][5].
+LIC_EXPORT int lic_stem_conv_bf16(const float* x, const void* w_packed, const float* bias, void* y, int32_t B, int32_t H,
+                                  int32_t W, int32_t Cout, lic_stream_t stream) {
+  if (!x || !w_packed || !y || B <= 0 || H <= 0 || W <= 0) return LIC_ERR_INVALID;
+  if (!(Cout == 64 || Cout == 128 || Cout == 192)) return LIC_ERR_UNSUPPORTED;
+  if (!st_al16(w_packed) || !st_al16(y) || (reinterpret_cast<uintptr_t>(x) & 3)) return LIC_ERR_INVALID;
+  StemParams p = {};
+  p.x = x;
+  p.w = (const bf16_t*)w_packed;
+  p.bias = bias;
+  p.y = (bf16_t*)y;
+  p.B = B;
+  p.H = H;
+  p.W = W;
+  p.Ho = (H + 1) / 2;
+  p.Wo = (W + 1) / 2;
+  p.P = (long)B * p.Ho * p.Wo;
+  if (p.P > 0x7FFFFFFFL / 2 || (long)B * H * W * 3 > 0x7FFFFFFFFFL) return LIC_ERR_UNSUPPORTED;
+  hipStream_t s = (hipStream_t)stream;
+  auto resident = [](const void* fn, int threads) {
+    int per_cu = 0, cus = 0, devid = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    if (hipGetDevice(&devid) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, devid) != hipSuccess || cus < 1)
+      cus = 256;
+    return per_cu * cus;
+  };
+  if (Cout == 192) {
+    static const int slots = resident((const void*)stem_gdn_bf16_kernel<6, 8, true>, 512);
+    p.ntiles = (int)((p.P + 255) / 256);
+    hipLaunchKernelGGL((stem_gdn_bf16_kernel<6, 8, true>), dim3(p.ntiles < slots ? p.ntiles : slots), dim3(512), 0, s, p);
+  } else if (Cout == 128) {
+    static const int slots = resident((const void*)stem_gdn_bf16_kernel<4, 4, true>, 256);
+    p.ntiles = (int)((p.P + 127) / 128);
+    hipLaunchKernelGGL((stem_gdn_bf16_kernel<4, 4, true>), dim3(p.ntiles < slots ? p.ntiles : slots), dim3(256), 0, s, p);
+  } else {
+    static const int slots = resident((const void*)stem_gdn_bf16_kernel<2, 4, true>, 256);
+    p.ntiles = (int)((p.P + 127) / 128);
+    hipLaunchKernelGGL((stem_gdn_bf16_kernel<2, 4, true>), dim3(p.ntiles < slots ? p.ntiles : slots), dim3(256), 0, s, p);
+  }
   return lic_check_launch();
 }
 

@@ -300,6 +300,12 @@ def _stem_backward_bf16(col, weight, g, Cin, need_dw, need_db):
     return dw, db
 
 
+def _head_direct(Cin, Cout, kh, kw, stride, pad, out_pad) -> bool:
+    if os.environ.get("LIC_BF16_HEAD_DIRECT", "1") == "0":
+        return False
+    return bool(L.load().lic_head_convt_bf16_supported(Cin, Cout, kh, kw, stride, pad, out_pad))
+
+
 class _ImageConvTBF16Fn(torch.autograd.Function):
     """RGB head (Components.py:45): bf16 activations -> bf16 per-tap columns -> fp32 image."""
 
@@ -317,30 +323,58 @@ class _ImageConvTBF16Fn(torch.autograd.Function):
             wd = torch.zeros((Cin, Kp), device=x.device, dtype=torch.float32)
             _permute3(weight.contiguous(), wd, (Cin, Cout, taps), (Cout * taps, taps, 1), (Kp, 1, Cout))
             wpk = _pack_bf16(wd, 1, Cin, Kp, 0, Kp, 1)
-        col = torch.empty((P, Kp), device=x.device, dtype=BF16)
-        _igemm_bf16(xh, wpk, col, B=1, Hi=1, Wi=P, Cin=Cin, Ho=1, Wo=P, Cout=Kp,
-                    kh=1, kw=1, stride=1, pad=0, transposed=False)
         out = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
-        L.check(lib.lic_col2im_bf16(_ptr(col), _ptr(bias), _ptr(out), B, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, pad,
-                                    Kp, _stream()), "lic_col2im_bf16")
+        direct = _head_direct(Cin, Cout, kh, kw, stride, pad, out_pad)
+        if direct:
+            # features -> image in one launch, no column matrix (lic_head_bf16.hip)
+            from . import functional as F_
+            if F_.KERNEL_TRACE is not None:
+                F_.KERNEL_TRACE.add(f"head_convt_bf16_kernel<{Cin // 16}>")
+            F_._timed(f"head_convt_bf16_kernel<{Cin // 16}>", 2 * P * Cin * taps * Cout, 2 * P * Cin + 4 * B * Ho * Wo * Cout,
+                      lambda: L.check(lib.lic_head_convt_bf16(_ptr(xh), _ptr(wpk), _ptr(bias), _ptr(out), B, Hi, Wi, Cin,
+                                                              _stream()), "lic_head_convt_bf16"))
+        else:
+            col = torch.empty((P, Kp), device=x.device, dtype=BF16)
+            _igemm_bf16(xh, wpk, col, B=1, Hi=1, Wi=P, Cin=Cin, Ho=1, Wo=P, Cout=Kp,
+                        kh=1, kw=1, stride=1, pad=0, transposed=False)
+            L.check(lib.lic_col2im_bf16(_ptr(col), _ptr(bias), _ptr(out), B, Hi, Wi, Cout, Ho, Wo, kh, kw, stride, pad,
+                                        Kp, _stream()), "lic_col2im_bf16")
         ctx.save_for_backward(xh, weight)
-        ctx.cfg = (stride, pad, (Ho, Wo), bias is not None, x.dtype)
+        ctx.cfg = (stride, pad, (Ho, Wo), bias is not None, x.dtype, direct)
         return _nchw_view(out)
 
     @staticmethod
     def backward(ctx, gy):
         xh, weight = ctx.saved_tensors
-        stride, pad, (Ho, Wo), has_bias, in_dtype = ctx.cfg
+        stride, pad, (Ho, Wo), has_bias, in_dtype, direct = ctx.cfg
         g = _nhwc(gy).float()
         B, Hi, Wi, Cin = xh.shape
         _, Cout, kh, kw = weight.shape
         taps, Kp, P = kh * kw, _kpad8(kh, kw, Cout), B * Hi * Wi
         lib = L.load()
-        dcol = torch.empty((P, Kp), device=g.device, dtype=BF16)
-        L.check(lib.lic_im2col_bf16(_ptr(g), _ptr(dcol), B, Ho, Wo, Cout, Hi, Wi, kh, kw, stride, pad, Kp, _stream()),
-                "lic_im2col_bf16")
         dx = dw = db = None
-        if ctx.needs_input_grad[0]:
+        if ctx.needs_input_grad[0] and direct and in_dtype == BF16:
+            # the data gradient = conv2d(dL/d image, the same [Cin][3][5][5] weight, stride 2, padding 2): one launch
+            # from the image gradient, no column matrix (lic_stem_conv_bf16)
+            wp16 = prepared(weight, "bf16.head_dx16")
+            if wp16 is None:
+                wp16 = torch.empty((lib.lic_stem_weight_bf16_elems(Cin),), device=g.device, dtype=BF16)
+                L.check(lib.lic_pack_stem_weight_bf16(_ptr(weight.contiguous()), _ptr(wp16), Cin, _stream()),
+                        "lic_pack_stem_weight_bf16")
+            dxh = torch.empty((B, Hi, Wi, Cin), device=g.device, dtype=BF16)
+            from . import functional as F_
+            if F_.KERNEL_TRACE is not None:
+                F_.KERNEL_TRACE.add(f"stem_gdn_bf16_kernel<{Cin // 32}, plain>")
+            L.check(lib.lic_stem_conv_bf16(_ptr(g), _ptr(wp16), None, _ptr(dxh), B, Ho, Wo, Cin, _stream()),
+                    "lic_stem_conv_bf16")
+            dx = _nchw_view(dxh)
+        need_dx_cols = ctx.needs_input_grad[0] and dx is None
+        dcol = None
+        if need_dx_cols or ctx.needs_input_grad[1]:
+            dcol = torch.empty((P, Kp), device=g.device, dtype=BF16)
+            L.check(lib.lic_im2col_bf16(_ptr(g), _ptr(dcol), B, Ho, Wo, Cout, Hi, Wi, kh, kw, stride, pad, Kp, _stream()),
+                    "lic_im2col_bf16")
+        if need_dx_cols:
             wpk = prepared(weight, "bf16.head_dx")
             if wpk is None:
                 wdT = torch.zeros((Kp, Cin), device=g.device, dtype=torch.float32)

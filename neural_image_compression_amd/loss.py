@@ -22,6 +22,7 @@ def rd_loss(model_out: dict, x: torch.Tensor, lambda_rd: float, sync: bool = Tru
     else:
         for i, k in enumerate(_KEYS[1:], start=1):
             res[k] = det[i]
+        res['_buffer'] = det   # (all of the above in one tensor: `det[:9].tolist()` is ONE device-to-host copy)
     res['mse_per_image'] = det[16:16 + B]
     res['psnr_per_image'] = det[16 + B:16 + 2 * B]
     return res

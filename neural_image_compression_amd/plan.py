@@ -30,7 +30,7 @@ from .functional import _stream
 
 class StepPlan:
     def __init__(self, model, loss_fn: Callable, lambda_val: float, example: torch.Tensor, warmup: int = 2,
-                 side_stream: Optional[torch.cuda.Stream] = None):
+                 side_stream: Optional[torch.cuda.Stream] = None, tune: bool = False):
         """`loss_fn(model_out, x, lambda_val, sync=False)` -> dict with 'loss' (loss.rd_loss); `example`: a batch
         of the shape every later batch will have.  Runs `warmup` eager steps WITHOUT an optimizer step (they fill
         the caches: packed-weight plan, gradient buffers, allocator), then captures one."""
@@ -45,6 +45,7 @@ class StepPlan:
         self._plan = C.c_void_p()
         self._lib = L.load()
         dev = example.device
+        gen_state = torch.cuda.get_rng_state(dev)   # (the probe and the warm-up draw noise: restored below)
         with torch.no_grad():
             probe = model.analysis_hyperprior(self.x, training=True) if hasattr(model, "analysis_hyperprior") \
                 else model(self.x)
@@ -58,7 +59,8 @@ class StepPlan:
                       self.u[nz:].view(Bn, hy, wy, Mc).permute(0, 3, 1, 2))
         del probe, y, z
         self.side = side_stream if side_stream is not None else torch.cuda.Stream(device=dev)
-        gen_state = torch.cuda.get_rng_state(dev)
+        self.side2 = torch.cuda.Stream(device=dev)
+        self._sides = (C.c_void_p * 2)(self.side.cuda_stream, self.side2.cuda_stream)
         cap = torch.cuda.Stream(device=dev)
         cap.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(cap):
@@ -75,17 +77,28 @@ class StepPlan:
             prep.invalidate()
         with torch.cuda.graph(self.graph, stream=cap):
             self.out, self.results = self._body()
-        torch.cuda.set_rng_state(gen_state, dev)   # (the warm-up draws are not part of the training run)
+        torch.cuda.set_rng_state(gen_state, dev)   # (building the plan leaves torch's generator where it found it)
         rc = self._lib.lic_plan_create(C.c_void_p(self.graph.raw_cuda_graph()), C.byref(self._plan))
         if rc != 0:
             why = self._lib.lic_plan_last_error().decode()
             self._plan = C.c_void_p()
             raise L.LicError(f"lic_plan_create failed: {L._STATUS.get(rc, rc)} ({why})")
-        info = (C.c_int64 * 6)()
+        self.tuning = None
+        if tune:
+            # time every operation, list-schedule onto the two streams, keep whichever schedule measures faster
+            # (a few dozen replays of the captured step: same inputs, same outputs)
+            r = (C.c_double * 4)()
+            rc = self._lib.lic_plan_tune(self._plan, _stream(), self._sides, 2, r)
+            if rc != 0:
+                raise L.LicError(f"lic_plan_tune failed: {L._STATUS.get(rc, rc)} ({self._lib.lic_plan_last_error().decode()})")
+            torch.cuda.synchronize(dev)
+            self.tuning = {"sum_of_operations_us": round(r[0], 1), "capture_order_us": round(r[1], 1),
+                           "tuned_us": round(r[2], 1), "tuned_kept": bool(r[3])}
+        info = (C.c_int64 * 7)()
         L.check(self._lib.lic_plan_info(self._plan, info), "lic_plan_info")
-        self.info = dict(zip(("nodes", "kernels", "memsets", "memcpys", "on_side_stream", "events"), list(info)))
+        self.info = dict(zip(("nodes", "kernels", "memsets", "memcpys", "on_side_stream", "events", "tuned"), list(info)))
         self.replays = 0
-        self.two_streams = True   # False: everything on the caller's stream (A/B, debugging)
+        self.streams = 3   # 1: everything on the caller's stream, 2: one side stream (A/B, debugging)
         self._params = list(model.parameters())
         self._grads = [p.grad for p in self._params]   # the captured step's gradient tensors: every replay rewrites them
 
@@ -118,7 +131,7 @@ class StepPlan:
             if p.grad is not g:
                 p.grad = g
         self.u.uniform_()
-        rc = self._lib.lic_plan_replay(self._plan, _stream(), C.c_void_p(self.side.cuda_stream) if self.two_streams else None)
+        rc = self._lib.lic_plan_replay(self._plan, _stream(), self._sides, self.streams - 1)
         if rc != 0:
             raise L.LicError(f"lic_plan_replay failed: {L._STATUS.get(rc, rc)} ({self._lib.lic_plan_last_error().decode()})")
         self.replays += 1

@@ -133,6 +133,12 @@ class StepPrep:
                 elif tr and cout < 4:       # RGB head: [Cin][taps*Cout] and its transpose for the data gradient
                     pack(w, "head", half, K=cin, N=taps * cout, s_k=cout * taps, ndiv=cout, s_n=1, s_nr=taps)
                     pack(w, "head_dx", half, K=taps * cout, N=cin, kdiv=cout, s_k=1, s_kr=taps, s_n=cout * taps)
+                    if half and lib.lic_head_convt_bf16_supported(cin, cout, kh, kw_, _pair(m.stride), _pair(m.padding),
+                                                                  _pair(m.output_padding)):
+                        # the data gradient as a direct convolution of the image gradient (lic_stem_conv_bf16)
+                        dst = torch.empty((lib.lic_stem_weight_bf16_elems(cin),), device=dev, dtype=BF16)
+                        job(L.PREP_PACK_BF16_STEM, w, dst, N=cin)
+                        entries.append((w, "bf16.head_dx16", dst))
                 else:
                     pack(w, "fwd", half, taps=taps, K=cin, N=cout, s_tap=1, s_k=s_ci, s_n=s_co, mask=mask)
                     pack(w, "dgrad", half, taps=taps, K=cout, N=cin, s_tap=1, s_k=s_co, s_n=s_ci, mask=mask)

@@ -412,6 +412,45 @@ def test_image_layers_bf16(env):
     scale_close(host(tbt.grad), dbf, 1e-4, "head db")
 
 
+# the RGB head without column matrices (lic_head_convt_bf16: features -> image in one launch; lic_stem_conv_bf16: its data
+# gradient as a direct convolution of the image gradient): partial tiles in both directions, every supported width,
+# against the oracle on bf16-exact operands (fp32 accumulation of exact products: tight) and against the column-matrix
+# route (which rounds the per-tap columns to bf16: its own tolerance)
+@pytest.mark.parametrize("C,B,Hi,Wi", [(64, 2, 5, 7), (128, 2, 9, 40), (128, 1, 8, 64), (192, 1, 6, 33), (128, 3, 1, 1)])
+def test_head_direct_bf16(env, monkeypatch, C, B, Hi, Wi):
+    nic, FB, O, d = env
+    from neural_image_compression_amd import functional as F_
+    r = np.random.RandomState(C + Hi + Wi)
+    xh = rb(r.randn(B, C, Hi, Wi).astype(np.float32))
+    wt = rb((r.randn(C, 3, 5, 5) / math.sqrt(C * 25)).astype(np.float32))
+    bt = r.randn(3).astype(np.float32)
+    g = r.randn(B, 3, 2 * Hi, 2 * Wi).astype(np.float32)
+
+    def run():
+        twt, tbt = dev(wt, d).contiguous().requires_grad_(True), dev(bt, d, grad=True)
+        txh = dev(xh, d, BF, grad=True)
+        F_.KERNEL_TRACE = set()
+        out = FB.image_conv_transpose2d_bf16(txh, twt, tbt, 2, 2, 1)
+        out.backward(dev(g, d))
+        names, F_.KERNEL_TRACE = F_.KERNEL_TRACE, None
+        return host(out), host(txh.grad), host(twt.grad), host(tbt.grad), names
+
+    out, dx, dw, db, names = run()
+    assert any("head_convt_bf16_kernel" in n for n in names) and any("plain" in n for n in names), names
+    out_ref = O.convT2d_fwd(xh, wt, bt, 2, 2, 1)
+    scale_close(out, out_ref, 2e-5, "head out (direct)")
+    dx_ref, dw_ref, _ = O.convT2d_bwd(xh, wt, rb(g), 2, 2, 1)
+    bf16_close(dx, dx_ref, "head dx (direct)")
+    scale_close(dw, dw_ref, 1e-4, "head dw")
+    scale_close(db, O.convT2d_bwd(xh, wt, g, 2, 2, 1)[2], 1e-4, "head db")
+    monkeypatch.setenv("LIC_BF16_HEAD_DIRECT", "0")
+    out2, dx2, dw2, db2, names2 = run()
+    assert not any("head_convt_bf16_kernel" in n for n in names2), names2
+    scale_close(out, out2, 2e-2, "direct vs column-matrix route: out")
+    scale_close(dx, dx2, 2e-2, "direct vs column-matrix route: dx")
+    assert np.array_equal(dw, dw2) and np.array_equal(db, db2)   # (the weight gradient still runs from the columns)
+
+
 @pytest.mark.parametrize("inverse", [False, True])
 def test_gdn_bf16(env, inverse):
     nic, FB, O, d = env

@@ -51,31 +51,42 @@ def test_plan_replays_a_fork_join_capture():
 
     plan = C.c_void_p()
     L.check(lib.lic_plan_create(C.c_void_p(g.raw_cuda_graph()), C.byref(plan)), "lic_plan_create")
-    info = (C.c_int64 * 6)()
+    info = (C.c_int64 * 7)()
     L.check(lib.lic_plan_info(plan, info), "lic_plan_info")
-    nodes, kernels, memsets, memcpys, on_side, events = list(info)
+    nodes, kernels, memsets, memcpys, on_side, events, tuned = list(info)
     assert nodes == kernels + memsets + memcpys and memcpys == 0 and on_side >= 3 and events >= 2, list(info)
-    s_main, s_side = torch.cuda.Stream(), torch.cuda.Stream()
+    s_main, s_side, s_side2 = torch.cuda.Stream(), torch.cuda.Stream(), torch.cuda.Stream()
+    sides = (C.c_void_p * 2)(s_side.cuda_stream, s_side2.cuda_stream)
     for trial in range(3):
         x.copy_(torch.arange(1 << 20, device=dev, dtype=torch.float32) * (trial + 1.5))
         torch.cuda.synchronize()
         with torch.cuda.stream(s_main):
-            L.check(lib.lic_plan_replay(plan, C.c_void_p(s_main.cuda_stream), C.c_void_p(s_side.cuda_stream)), "replay")
+            L.check(lib.lic_plan_replay(plan, C.c_void_p(s_main.cuda_stream), sides, 1), "replay")
             got = e.clone()              # queued on `main` after the call: ordered after ALL of the plan
         torch.cuda.synchronize()
         assert torch.equal(got, expect(x)), trial
+    # the tuned schedule (whichever of the two it keeps) computes the same thing
+    r = (C.c_double * 4)()
+    L.check(lib.lic_plan_tune(plan, C.c_void_p(s_main.cuda_stream), sides, 2, r), "lic_plan_tune")
+    torch.cuda.synchronize()
+    assert r[0] > 0 and r[1] > 0 and r[2] > 0 and r[3] in (0.0, 1.0)
+    x.add_(3.0)
+    torch.cuda.synchronize()
+    L.check(lib.lic_plan_replay(plan, C.c_void_p(s_main.cuda_stream), sides, 1), "replay")
+    torch.cuda.synchronize()
+    assert torch.equal(e, expect(x))
     # one stream: the same plan, serialised
     x.mul_(0.25)
     torch.cuda.synchronize()
-    L.check(lib.lic_plan_replay(plan, C.c_void_p(s_main.cuda_stream), None), "replay")
+    L.check(lib.lic_plan_replay(plan, C.c_void_p(s_main.cuda_stream), None, 0), "replay")
     torch.cuda.synchronize()
     assert torch.equal(e, expect(x))
     lib.lic_plan_destroy(plan)
     assert lib.lic_plan_create(None, C.byref(plan)) == -1     # LIC_ERR_INVALID
 
 
-@pytest.mark.parametrize("precision,M,K", [("bf16", 128, 3), ("fp32", 64, 1)])
-def test_step_plan_equals_eager_training(precision, M, K):
+@pytest.mark.parametrize("precision,M,K,tune", [("bf16", 128, 3, True), ("bf16", 128, 3, False), ("fp32", 64, 1, True)])
+def test_step_plan_equals_eager_training(precision, M, K, tune):
     """five optimizer steps from the same seed, eager and planned: every loss and every parameter bit for bit"""
     _need_gpu()
     import neural_image_compression_amd as nic
@@ -103,7 +114,8 @@ def test_step_plan_equals_eager_training(precision, M, K):
         losses_a.append(float(res["loss"].detach()))
 
     mb, ob = build()
-    plan = StepPlan(mb, nic.rd_loss, lam, xs[0])
+    plan = StepPlan(mb, nic.rd_loss, lam, xs[0], tune=tune)
+    assert (plan.tuning is not None) == tune
     assert plan.info["kernels"] > 100 and plan.info["on_side_stream"] > 10 and plan.info["events"] >= 2, plan.info
     torch.cuda.manual_seed(5)
     losses_b = []
@@ -124,3 +136,46 @@ def test_step_plan_equals_eager_training(precision, M, K):
         ea, eb = ma(xs[0], training=False)["x_hat"], mb(xs[0], training=False)["x_hat"]
     assert torch.equal(ea, eb)
     plan.close()
+
+
+def test_trainer_with_step_plan_trains_like_the_eager_trainer(tmp_path):
+    """Trainer(step_plan=True): same parameters and the same logged numbers as the eager trainer after a short run that
+    ends on a batch of another shape (which takes the eager step)"""
+    _need_gpu()
+    import neural_image_compression_amd as nic
+    from neural_image_compression_amd.trainer import Trainer
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(21)
+    batches = [torch.rand(4, 3, 64, 64, generator=g) for _ in range(3)] + [torch.rand(2, 3, 64, 64, generator=g)]
+
+    class Log:
+        def __init__(self):
+            self.rows = []
+
+        def add_scalar(self, tag, value, step):
+            self.rows.append((tag, value, step))
+
+        def close(self):
+            pass
+
+    def run(step_plan):
+        torch.manual_seed(2)
+        m = nic.JointAutoregressiveHierarchical(128, 3).to(dev)
+        m.set_precision("bf16")
+        log = Log()
+        tr = Trainer(m, nic.FusedAdam(m.parameters(), lr=1e-3), batches, rd_loss=nic.rd_loss, lambda_val=0.01, max_steps=4,
+                     checkpoint_path=None, writer=log, step_plan=step_plan, log_interval=100, img_interval=100,
+                     val_interval=100)
+        tr.log_statistics = False
+        torch.cuda.manual_seed(9)
+        tr.train()
+        return m, log.rows, tr
+
+    ma, rows_a, _ = run(False)
+    mb, rows_b, trb = run(True)
+    assert trb._plan is not None and trb._plan.replays == 3
+    for (n, pa), pb in zip(ma.named_parameters(), mb.parameters()):
+        assert torch.equal(pa.detach(), pb.detach()), n
+    la = [(t, v, s) for t, v, s in rows_a if t.startswith("losses/")]
+    lb = [(t, v, s) for t, v, s in rows_b if t.startswith("losses/")]
+    assert la == lb and len(la) == 4 * 8   # (the loss itself is a tensor: the eight plain numbers per step)

@@ -81,7 +81,7 @@ def main():
     lp = [float(v) for v in losses_p]
     ms1, enq1 = timeit(lambda: plan.step(x), steps)
     print(f"cfg{cfg} plan, replay only (no optimizer): {ms1:7.3f} ms/step, host enqueue {enq1:6.3f} ms/step", flush=True)
-    plan.two_streams = False
+    plan.streams = 1
     ms1, enq1 = timeit(lambda: plan.step(x), steps)
     print(f"cfg{cfg} plan on ONE stream, replay only : {ms1:7.3f} ms/step, host enqueue {enq1:6.3f} ms/step", flush=True)
     same = sum(a == b for a, b in zip(le, lp))

@@ -19,8 +19,8 @@ cfg = sys.argv[1] if len(sys.argv) > 1 else "3"
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 dev = torch.device("cuda", 0)
 model, opt, x, lam, B = build(cfg, dev)
-plan = StepPlan(model, nic.rd_loss, lam, x)
-plan.two_streams = (sys.argv[3] if len(sys.argv) > 3 else "2") == "2"
+plan = StepPlan(model, nic.rd_loss, lam, x, tune=os.environ.get("LIC_PLAN_TUNE", "0") == "1")
+plan.streams = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 
 
 def step():
@@ -41,4 +41,4 @@ for _ in range(3):
     step()
 ms, enq = timeit(step, steps)
 print(mode, end=": ")
-print(f"cfg{cfg} plan ({'two streams' if plan.two_streams else 'one stream'}): {ms:.3f} ms/step, host enqueue {enq:.3f} ms/step; {plan.info}")
+print(f"cfg{cfg} plan ({plan.streams} streams): {ms:.3f} ms/step, host enqueue {enq:.3f} ms/step; {plan.info} {plan.tuning}")
