@@ -473,6 +473,41 @@ int lic_adam_run(const lic_adam_job* jobs_device, int32_t njobs, int64_t total_b
                  double bias_correction2, lic_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * lic_reduce_batch -- every pending reduction of a backward pass (Trainer.py:84 `loss.backward()`) in ONE launch.
+ *   The weight-gradient launches end in a slab reduction and the column sums (bias / GDN beta gradients) in a second
+ *   stage: 41 launches of 5-15 us per config-3 step.  lic_wgrad_bf16_partial / lic_colsum_bf16_partial /
+ *   lic_colsum2_bf16_partial launch the first stage only and fill a lic_reduce_job; lic_reduce_batch(jobs, n) -- `jobs` a
+ *   HOST array, copied into the kernel arguments, LIC_REDUCE_MAX_JOBS per launch -- finishes them with the arithmetic
+ *   and association order of the stand-alone second stages (bitwise the same results), optionally followed per element
+ *   by the GDN re-parametrisation's backward (epilogue LIC_REDUCE_EPI_REPARAM: lic_gdn_reparam_bwd with `param`, `bound`
+ *   on the reduced value, `param` indexed like `dst`) and with split destination indices (mdiv / ndiv as in lic_prep_job:
+ *   offset(m) = mdiv ? (m / mdiv) * sm + (m % mdiv) * smr : m * sm; rows >= Mvalid / columns >= Nvalid are dropped):
+ *   the (tap, channel) <-> column maps of the RGB layers' weight gradients.  Workspaces and outputs named by a job must
+ *   stay alive until the batch has been launched; block0 / nblocks are filled by lic_reduce_batch.
+ * ------------------------------------------------------------------------------------------ */
+enum { LIC_REDUCE_SLABS = 0, LIC_REDUCE_COLUMNS = 1 };
+enum { LIC_REDUCE_EPI_NONE = 0, LIC_REDUCE_EPI_REPARAM = 1 };
+#define LIC_REDUCE_MAX_JOBS 32
+typedef struct lic_reduce_job {
+  const float* src;   /* SLABS: [splitk][ntaps * Cm * Cn]; COLUMNS: [splitk][Cn] */
+  float* dst;
+  const float* param; /* epilogue REPARAM */
+  int64_t sm, smr, sn, snr, stap;
+  int32_t kind, epilogue;
+  int32_t splitk, ntaps, Cm, Cn, Mvalid, Nvalid, mdiv, ndiv;
+  float scale, bound;
+  int32_t block0, nblocks;
+} lic_reduce_job;
+int lic_wgrad_bf16_partial(const lic_wgrad_desc* d, void* workspace, size_t workspace_bytes, lic_reduce_job* job,
+                           lic_stream_t stream);
+int lic_colsum_bf16_partial(const void* in, int64_t ld, int64_t P, int32_t C, float scale, float* out, void* workspace,
+                            size_t workspace_bytes, lic_reduce_job* job, lic_stream_t stream);
+int lic_colsum2_bf16_partial(const void* in_a, const void* in_b, int64_t ld, int64_t P, int32_t C, float scale,
+                             float* out_a, float* out_b, void* workspace, size_t workspace_bytes, lic_reduce_job* jobs2,
+                             lic_stream_t stream);
+int lic_reduce_batch(const lic_reduce_job* jobs, int32_t njobs, lic_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * RGB head in bf16 storage without column matrices (Components.py:45: ConvTranspose2d(C, 3, 5, stride 2, padding 2,
  *   output_padding 1); the column-matrix route of lic_igemm_bf16 + lic_col2im_bf16 / lic_im2col_bf16 remains for
  *   other geometries).

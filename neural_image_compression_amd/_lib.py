@@ -55,6 +55,21 @@ class PrepJob(C.Structure):
                 ("total", _i64)]
 
 
+REDUCE_SLABS, REDUCE_COLUMNS = 0, 1
+REDUCE_EPI_NONE, REDUCE_EPI_REPARAM = 0, 1
+REDUCE_MAX_JOBS = 32
+
+
+class ReduceJob(C.Structure):
+    _fields_ = [("src", _vp), ("dst", _vp), ("param", _vp),
+                ("sm", _i64), ("smr", _i64), ("sn", _i64), ("snr", _i64), ("stap", _i64),
+                ("kind", _i32), ("epilogue", _i32),
+                ("splitk", _i32), ("ntaps", _i32), ("Cm", _i32), ("Cn", _i32), ("Mvalid", _i32), ("Nvalid", _i32),
+                ("mdiv", _i32), ("ndiv", _i32),
+                ("scale", _f32), ("bound", _f32),
+                ("block0", _i32), ("nblocks", _i32)]
+
+
 class AdamJob(C.Structure):
     _fields_ = [("p", _vp), ("g", _vp), ("m", _vp), ("v", _vp), ("n", _i64), ("block0", _i32), ("nblocks", _i32)]
 
@@ -114,6 +129,10 @@ SIGNATURES = {
     "lic_col2im_bf16": (C.c_int, [_vp, _vp, _vp] + [_i32] * 11 + [_vp]),
     "lic_colsum_bf16_workspace_bytes": (_sz, [_i64, _i32]),
     "lic_colsum_bf16": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _vp, _vp, _sz, _vp]),
+    "lic_wgrad_bf16_partial": (C.c_int, [C.POINTER(WgradDesc), _vp, _sz, C.POINTER(ReduceJob), _vp]),
+    "lic_colsum_bf16_partial": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _vp, _vp, _sz, C.POINTER(ReduceJob), _vp]),
+    "lic_colsum2_bf16_partial": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _f32, _vp, _vp, _vp, _sz, C.POINTER(ReduceJob), _vp]),
+    "lic_reduce_batch": (C.c_int, [C.POINTER(ReduceJob), _i32, _vp]),
     "lic_colsum2_bf16": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _f32, _vp, _vp, _vp, _sz, _vp]),
     "lic_gdn_dnorm_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "lic_gdn_bwd_bf16_supported": (C.c_int, [_i32]),

@@ -166,6 +166,45 @@ LIC_EXPORT int lic_colsum_bf16(const void* in, int64_t ld, int64_t P, int32_t C,
                      scale, out, (float*)nullptr);
   return lic_check_launch();
 }
+// stage 1 only; `job` (two of them for the pair variant) receives stage 2 for a later lic_reduce_batch
+LIC_EXPORT int lic_colsum_bf16_partial(const void* in, int64_t ld, int64_t P, int32_t C, float scale, float* out,
+                                       void* workspace, size_t workspace_bytes, lic_reduce_job* job, lic_stream_t stream) {
+  if (!in || !out || !workspace || !job || P <= 0 || C <= 0) return LIC_ERR_INVALID;
+  if (C % 8 || ld % 8 || (reinterpret_cast<uintptr_t>(in) & 15)) return LIC_ERR_UNSUPPORTED;
+  const int nchunk = csh_chunks(P);
+  if (workspace_bytes < (size_t)nchunk * C * sizeof(float)) return LIC_ERR_WORKSPACE;
+  hipLaunchKernelGGL(colsum_bf16_stage1, dim3((C + 63) / 64, nchunk), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in,
+                     (const bf16_t*)nullptr, (long)ld, (long)P, C, (float*)workspace, nchunk);
+  *job = lic_reduce_job{};
+  job->src = (const float*)workspace;
+  job->dst = out;
+  job->kind = LIC_REDUCE_COLUMNS;
+  job->splitk = nchunk;
+  job->Cn = C;
+  job->scale = scale;
+  return lic_check_launch();
+}
+LIC_EXPORT int lic_colsum2_bf16_partial(const void* in_a, const void* in_b, int64_t ld, int64_t P, int32_t C, float scale,
+                                        float* out_a, float* out_b, void* workspace, size_t workspace_bytes,
+                                        lic_reduce_job* jobs2, lic_stream_t stream) {
+  if (!in_a || !in_b || !out_a || !out_b || !workspace || !jobs2 || P <= 0 || C <= 0) return LIC_ERR_INVALID;
+  if (C % 8 || ld % 8 || (reinterpret_cast<uintptr_t>(in_a) & 15) || (reinterpret_cast<uintptr_t>(in_b) & 15))
+    return LIC_ERR_UNSUPPORTED;
+  const int nchunk = csh_chunks(P);
+  if (workspace_bytes < 2 * (size_t)nchunk * C * sizeof(float)) return LIC_ERR_WORKSPACE;
+  hipLaunchKernelGGL(colsum_bf16_stage1, dim3((C + 63) / 64, nchunk, 2), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)in_a, (const bf16_t*)in_b, (long)ld, (long)P, C, (float*)workspace, nchunk);
+  for (int k = 0; k < 2; ++k) {
+    jobs2[k] = lic_reduce_job{};
+    jobs2[k].src = (const float*)workspace + (k ? (long)nchunk * C : 0L);
+    jobs2[k].dst = k ? out_b : out_a;
+    jobs2[k].kind = LIC_REDUCE_COLUMNS;
+    jobs2[k].splitk = nchunk;
+    jobs2[k].Cn = C;
+    jobs2[k].scale = scale;
+  }
+  return lic_check_launch();
+}
 // column sums of TWO bf16 [P][ld] matrices of one shape in one launch pair (the d-beta and d-bias sums of a
 // conv -> GDN pair's backward: t = dL/dnorm and dL/d(conv output)); workspace: 2 x lic_colsum_bf16_workspace_bytes
 LIC_EXPORT int lic_colsum2_bf16(const void* in_a, const void* in_b, int64_t ld, int64_t P, int32_t C, float scale,

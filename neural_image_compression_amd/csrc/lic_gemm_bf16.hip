@@ -1351,8 +1351,8 @@ LIC_EXPORT int lic_wgrad_bf16_kernel_name(const lic_wgrad_desc* d, char* buf, si
   return LIC_OK;
 }
 // p / g are bf16 activations; dst and the workspace are fp32
-LIC_EXPORT int lic_wgrad_bf16(const lic_wgrad_desc* d, void* workspace, size_t workspace_bytes,
-                              lic_stream_t stream) {
+static int wgrad_bf16_impl(const lic_wgrad_desc* d, void* workspace, size_t workspace_bytes, lic_reduce_job* job,
+                           lic_stream_t stream) {
   WgHPlan pl;
   int rc = wgh_plan(d, &pl);
   if (rc != LIC_OK) return rc;
@@ -1417,8 +1417,130 @@ LIC_EXPORT int lic_wgrad_bf16(const lic_wgrad_desc* d, void* workspace, size_t w
   rc = lic_check_launch();
   if (rc != LIC_OK) return rc;
   const long total = (long)pl.ntaps * pl.Cm * pl.Cn;
+  if (job) {  // the slab reduction is left to a later lic_reduce_batch
+    *job = lic_reduce_job{};
+    job->src = (const float*)workspace;
+    job->dst = d->dst;
+    job->kind = LIC_REDUCE_SLABS;
+    job->splitk = pl.splitk;
+    job->ntaps = pl.ntaps;
+    job->Cm = pl.Cm;
+    job->Cn = pl.Cn;
+    job->Mvalid = pl.Cm;
+    job->Nvalid = pl.Cn;
+    job->sm = d->dst_sm;
+    job->sn = d->dst_sn;
+    job->stap = d->dst_stap;
+    job->scale = d->scale;
+    return LIC_OK;
+  }
   hipLaunchKernelGGL(wgrad_bf16_reduce_kernel, dim3(ew_grid(total, 256)), dim3(256), 0, s, (const float*)workspace,
                      d->dst, pl.splitk, pl.ntaps, pl.Cm, pl.Cn, (long)d->dst_sm, (long)d->dst_sn, (long)d->dst_stap,
                      d->scale);
   return lic_check_launch();
+}
+LIC_EXPORT int lic_wgrad_bf16(const lic_wgrad_desc* d, void* workspace, size_t workspace_bytes,
+                              lic_stream_t stream) {
+  return wgrad_bf16_impl(d, workspace, workspace_bytes, nullptr, stream);
+}
+// the MFMA launch only; `job` receives the slab reduction for a later lic_reduce_batch (the workspace must live until then)
+LIC_EXPORT int lic_wgrad_bf16_partial(const lic_wgrad_desc* d, void* workspace, size_t workspace_bytes,
+                                      lic_reduce_job* job, lic_stream_t stream) {
+  if (!job) return LIC_ERR_INVALID;
+  return wgrad_bf16_impl(d, workspace, workspace_bytes, job, stream);
+}
+
+// ---- lic_reduce_batch: every pending reduction of a backward pass in ONE launch -------------------------------------
+// A step of the bf16 configurations ends 24 weight-gradient launches with a slab reduction and 17 column-sum launches
+// with a second stage: 41 launches of 5-15 us each (15 % of the step's kernel time) whose arithmetic is tiny.  The
+// producers can leave them pending (lic_wgrad_bf16_partial, lic_colsum*_bf16_partial fill a lic_reduce_job); this
+// kernel runs a table of them -- same per-element arithmetic and association order as the stand-alone kernels, so the
+// results are bitwise theirs -- with the two things that sit behind a reduction folded in: the GDN
+// re-parametrisation's backward (epilogue 1: lic_gdn_reparam_bwd on the reduced value) and the (tap, channel) <-> column
+// index maps of the RGB layers' weight gradients (mdiv / ndiv: the split index of lic_prep_job).
+struct ReduceTable {
+  lic_reduce_job j[LIC_REDUCE_MAX_JOBS];
+  int n;
+};
+__global__ __launch_bounds__(256) void reduce_batch_kernel(const ReduceTable tb) {
+  int ji = 0;
+  while (ji + 1 < tb.n && (int)blockIdx.x >= tb.j[ji + 1].block0) ++ji;
+  const lic_reduce_job& q = tb.j[ji];
+  const int blk = (int)blockIdx.x - q.block0;
+  if (q.kind == LIC_REDUCE_SLABS) {
+    const long total = (long)q.ntaps * q.Cm * q.Cn;
+    for (long i = (long)blk * 256 + threadIdx.x; i < total; i += (long)q.nblocks * 256) {
+      float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      int z = 0;
+      for (; z + 8 <= q.splitk; z += 8) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a8[k] += q.src[(long)(z + k) * total + i];
+      }
+      for (; z < q.splitk; ++z) a8[0] += q.src[(long)z * total + i];
+      const float acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+      const int n = (int)(i % q.Cn);
+      const long t2 = i / q.Cn;
+      const int m = (int)(t2 % q.Cm);
+      const int tap = (int)(t2 / q.Cm);
+      if (m >= q.Mvalid || n >= q.Nvalid) continue;
+      const long mo = q.mdiv ? (long)(m / q.mdiv) * q.sm + (long)(m % q.mdiv) * q.smr : (long)m * q.sm;
+      const long no = q.ndiv ? (long)(n / q.ndiv) * q.sn + (long)(n % q.ndiv) * q.snr : (long)n * q.sn;
+      const long o = mo + no + tap * q.stap;
+      float v = acc * q.scale;
+      if (q.epilogue == LIC_REDUCE_EPI_REPARAM) {
+        const float pv = q.param[o], w = pv > q.bound ? pv : q.bound;
+        const float g = v * 2.0f * w;
+        v = (pv >= q.bound || g < 0.0f) ? g : 0.0f;
+      }
+      q.dst[o] = v;
+    }
+  } else {  // column partials [splitk = nchunk][Cn = C] -> dst[c]: colsum_bf16_stage2's arithmetic, 16 columns per block
+    __shared__ double red[16][17];
+    const int cx = threadIdx.x & 15, ly = threadIdx.x >> 4;
+    const int c = blk * 16 + cx;
+    double acc = 0.0;
+    if (c < q.Cn)
+      for (int y = ly; y < q.splitk; y += 16) acc += (double)q.src[(long)y * q.Cn + c];
+    red[ly][cx] = acc;
+    __syncthreads();
+    if (ly == 0 && c < q.Cn) {
+      double t = 0.0;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t += red[k][cx];
+      float v = (float)(t * (double)q.scale);
+      if (q.epilogue == LIC_REDUCE_EPI_REPARAM) {
+        const float pv = q.param[c], w = pv > q.bound ? pv : q.bound;
+        const float g = v * 2.0f * w;
+        v = (pv >= q.bound || g < 0.0f) ? g : 0.0f;
+      }
+      q.dst[c] = v;
+    }
+  }
+}
+LIC_EXPORT int lic_reduce_batch(const lic_reduce_job* jobs, int32_t njobs, lic_stream_t stream) {
+  if (njobs < 0 || (njobs > 0 && !jobs)) return LIC_ERR_INVALID;
+  for (int base = 0; base < njobs; base += LIC_REDUCE_MAX_JOBS) {
+    ReduceTable tb;
+    tb.n = njobs - base < LIC_REDUCE_MAX_JOBS ? njobs - base : LIC_REDUCE_MAX_JOBS;
+    int blocks = 0;
+    for (int i = 0; i < tb.n; ++i) {
+      lic_reduce_job q = jobs[base + i];
+      if (!q.src || !q.dst || q.splitk <= 0 || q.Cn <= 0 || (q.epilogue == LIC_REDUCE_EPI_REPARAM && !q.param)) return LIC_ERR_INVALID;
+      if (q.kind == LIC_REDUCE_SLABS) {
+        if (q.ntaps <= 0 || q.Cm <= 0) return LIC_ERR_INVALID;
+        q.nblocks = ew_grid((long)q.ntaps * q.Cm * q.Cn, 256);
+      } else if (q.kind == LIC_REDUCE_COLUMNS) {
+        q.nblocks = (q.Cn + 15) / 16;
+      } else {
+        return LIC_ERR_INVALID;
+      }
+      q.block0 = blocks;
+      blocks += q.nblocks;
+      tb.j[i] = q;
+    }
+    hipLaunchKernelGGL(reduce_batch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, tb);
+    const int rc = lic_check_launch();
+    if (rc != LIC_OK) return rc;
+  }
+  return LIC_OK;
 }

@@ -10,6 +10,7 @@ No CPU fallback: a non-CUDA tensor or a missing extension raises.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Optional, Tuple
 
 import torch
@@ -54,6 +55,58 @@ def _stream():
 
 def _ptr(t: Optional[torch.Tensor]):
     return None if t is None else C.c_void_p(t.data_ptr())
+
+
+# ------------------------------------------------------------------------------------------
+# reductions left pending until the end of a backward pass (lic_reduce_batch, include/lic.h)
+# ------------------------------------------------------------------------------------------
+DEFER_REDUCTIONS = os.environ.get("LIC_DEFER_REDUCTIONS", "1") != "0"
+_PENDING_JOBS = []   # L.ReduceJob of the running backward pass
+_PENDING_KEEP = []   # tensors they name: partial sums, outputs, parameters
+_PENDING_SEEN = set()
+
+
+def flush_reductions():
+    """launch every pending reduction (one lic_reduce_batch); autograd calls this at the end of a backward pass, on the
+    caller's stream, after that stream has been made to wait for every stream gradients were produced on"""
+    if _PENDING_JOBS:
+        n = len(_PENDING_JOBS)
+        arr = (L.ReduceJob * n)(*_PENDING_JOBS)
+        del _PENDING_JOBS[:]
+        try:
+            L.check(L.load().lic_reduce_batch(arr, n, _stream()), "lic_reduce_batch")
+        finally:
+            del _PENDING_KEEP[:]
+    _PENDING_SEEN.clear()
+
+
+def can_defer(*params) -> bool:
+    """May the reductions behind the gradients of `params` wait for the end of this backward pass?  Only if nothing
+    reads such a gradient earlier: no data-parallel bucket hooks (they fire per gradient), the parameter has no
+    gradient yet (autograd would ADD to it on arrival) and has not been met before in this pass (two uses of one
+    parameter are summed when the second arrives: everything pending is flushed first), and we are inside a backward
+    pass of the autograd engine (the flush is its final callback).  The pending job names the gradient tensor's memory
+    but holds no reference to the tensor: autograd adopts a returned gradient as `.grad` only while nobody else holds it
+    (otherwise it would COPY it -- before the reduction has run)."""
+    if not DEFER_REDUCTIONS or GRAD_VIEWS:
+        return False
+    ps = [p for p in params if p is not None]
+    if not all(p.is_leaf for p in ps):   # a derived weight: its gradient is READ by the next backward node
+        return False
+    if any(p.grad is not None or id(p) in _PENDING_SEEN for p in ps):
+        flush_reductions()
+        return False
+    try:
+        torch.autograd.Variable._execution_engine.queue_callback(flush_reductions)
+    except RuntimeError:
+        return False
+    _PENDING_SEEN.update(id(p) for p in ps)
+    return True
+
+
+def defer(job, *keep):
+    _PENDING_JOBS.append(job)
+    _PENDING_KEEP.extend(t for t in keep if t is not None)
 
 
 def _require_cuda(*ts):

@@ -107,7 +107,9 @@ def _igemm_bf16(inp, w_packed, out, *, B, Hi, Wi, Cin, Ho, Wo, Cout, kh, kw, str
 
 
 def _wgrad_bf16(p, g, dst, *, B, Hs, Ws, Cp, Hl, Wl, Cg, kh, kw, stride, pad, g_is_row, dst_sm, dst_sn, dst_stap,
-                sq_g=0):
+                sq_g=0, job=None):
+    """`job` (an L.ReduceJob): launch the MFMA kernel only and fill `job` with the slab reduction, for
+    functional.defer (the caller may still set its epilogue / index-map fields); None: reduce right away"""
     d = L.WgradDesc()
     d.p, d.g, d.dst = _ptr(p), _ptr(g), _ptr(dst)
     d.p_ld, d.g_ld = Cp, Cg
@@ -121,37 +123,73 @@ def _wgrad_bf16(p, g, dst, *, B, Hs, Ws, Cp, Hl, Wl, Cg, kh, kw, stride, pad, g_
     from . import functional as F_
     if F_.KERNEL_TRACE is not None:
         F_.KERNEL_TRACE.add(F_._kernel_name(lib.lic_wgrad_bf16_kernel_name, d))
+    def launch():
+        if job is None:
+            L.check(lib.lic_wgrad_bf16(C.byref(d), _ptr(ws), nbytes, _stream()), "lic_wgrad_bf16")
+        else:
+            L.check(lib.lic_wgrad_bf16_partial(C.byref(d), _ptr(ws), nbytes, C.byref(job), _stream()),
+                    "lic_wgrad_bf16_partial")
+            F_.defer(job, ws, p, g)   # (not `dst`: autograd adopts a gradient tensor only if nobody else holds it)
     if F_.PROFILE is None or 2.0 * B * Hs * Ws * kh * kw * Cp * Cg < F_.PROFILE_MIN_FLOP:
-        L.check(lib.lic_wgrad_bf16(C.byref(d), _ptr(ws), nbytes, _stream()), "lic_wgrad_bf16")
+        launch()
         return
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    L.check(lib.lic_wgrad_bf16(C.byref(d), _ptr(ws), nbytes, _stream()), "lic_wgrad_bf16")
+    launch()
     e1.record()
     nkey = ("w", B, Hs, Ws, Cp, Hl, Wl, Cg, kh, kw, stride, pad, bool(g_is_row), sq_g)
     name = _NAMES.get(nkey)
     if name is None:
         name = _NAMES[nkey] = F_._kernel_name(lib.lic_wgrad_bf16_kernel_name, d) + "+reduce"
+    if job is not None:
+        name = name[:-len("+reduce")]
     F_.PROFILE.append((name, 2 * B * Hs * Ws * kh * kw * Cp * Cg,
                        2 * (B * Hs * Ws * Cp + B * Hl * Wl * Cg), e0, e1))
 
 
-def _colsum_bf16(t2d, P, Cc):
+def _reparam_epilogue(job, param_c, bound):
+    job.epilogue, job.param, job.bound = L.REDUCE_EPI_REPARAM, param_c.data_ptr(), bound
+
+
+def _colsum_bf16(t2d, P, Cc, defer=False, reparam=None):
+    """column sums; `defer`: stage 2 joins the backward pass's batched reduction (functional.defer); `reparam` =
+    (parameter, bound): followed by the GDN re-parametrisation's backward (deferred mode only)"""
     lib = L.load()
     nbytes = lib.lic_colsum_bf16_workspace_bytes(P, Cc)
     ws = torch.empty((nbytes + 3) // 4, device=t2d.device, dtype=torch.float32)
     out = torch.empty((Cc,), device=t2d.device, dtype=torch.float32)
+    if defer:
+        from . import functional as F_
+        job = L.ReduceJob()
+        L.check(lib.lic_colsum_bf16_partial(_ptr(t2d), Cc, P, Cc, 1.0, _ptr(out), _ptr(ws), nbytes, C.byref(job), _stream()),
+                "lic_colsum_bf16_partial")
+        if reparam is not None:
+            _reparam_epilogue(job, *reparam)
+        F_.defer(job, ws, t2d, reparam[0] if reparam is not None else None)
+        return out
     L.check(lib.lic_colsum_bf16(_ptr(t2d), Cc, P, Cc, 1.0, _ptr(out), _ptr(ws), nbytes, _stream()),
             "lic_colsum_bf16")
     return out
 
 
-def _colsum2_bf16(a2d, b2d, P, Cc):
-    """column sums of two bf16 [P][Cc] matrices in one launch pair"""
+def _colsum2_bf16(a2d, b2d, P, Cc, defer=False, reparam_a=None):
+    """column sums of two bf16 [P][Cc] matrices in one launch pair (`defer` / `reparam_a`: as _colsum_bf16, the
+    re-parametrisation applies to the first matrix's sums)"""
     lib = L.load()
     nbytes = 2 * lib.lic_colsum_bf16_workspace_bytes(P, Cc)
     ws = torch.empty((nbytes + 3) // 4, device=a2d.device, dtype=torch.float32)
     out = torch.empty((2, Cc), device=a2d.device, dtype=torch.float32)
+    if defer:
+        from . import functional as F_
+        jobs = (L.ReduceJob * 2)()
+        L.check(lib.lic_colsum2_bf16_partial(_ptr(a2d), _ptr(b2d), Cc, P, Cc, 1.0, _ptr(out[0]), _ptr(out[1]), _ptr(ws),
+                                             nbytes, jobs, _stream()), "lic_colsum2_bf16_partial")
+        ja, jb = L.ReduceJob.from_buffer_copy(jobs[0]), L.ReduceJob.from_buffer_copy(jobs[1])
+        if reparam_a is not None:
+            _reparam_epilogue(ja, *reparam_a)
+        F_.defer(ja, ws, a2d, b2d, reparam_a[0] if reparam_a is not None else None)
+        F_.defer(jb)
+        return out[0], out[1]
     L.check(lib.lic_colsum2_bf16(_ptr(a2d), _ptr(b2d), Cc, P, Cc, 1.0, _ptr(out[0]), _ptr(out[1]), _ptr(ws), nbytes,
                                  _stream()), "lic_colsum2_bf16")
     return out[0], out[1]
@@ -224,16 +262,21 @@ def _conv_backward_bf16(xh, weight, g, stride, pad, transposed, in_dtype, tap_ma
         _igemm_bf16(g, wp, dxh, B=B, Hi=Ho, Wi=Wo, Cin=Cout, Ho=Hi, Wo=Wi, Cout=Cin, kh=kh, kw=kw, stride=stride,
                     pad=pad, transposed=not transposed, tap_mask=tap_mask)
         dx = _nchw_view(dxh)
+    # the slab reduction of the weight gradient and the second stage of the bias sum wait for the end of the backward
+    # pass when nothing can read these gradients earlier (functional.can_defer): one batched launch instead of ~40
+    from . import functional as F_
+    dfr = (need_dw or need_db) and F_.can_defer(weight)
     if need_dw:
         dw = grad_like(weight)
+        job = L.ReduceJob() if dfr else None
         if transposed:
             _wgrad_bf16(xh, g, dw, B=B, Hs=Hi, Ws=Wi, Cp=Cin, Hl=Ho, Wl=Wo, Cg=Cout, kh=kh, kw=kw, stride=stride,
-                        pad=pad, g_is_row=False, dst_sm=Cout * taps, dst_sn=taps, dst_stap=1)
+                        pad=pad, g_is_row=False, dst_sm=Cout * taps, dst_sn=taps, dst_stap=1, job=job)
         else:
             _wgrad_bf16(g, xh, dw, B=B, Hs=Ho, Ws=Wo, Cp=Cout, Hl=Hi, Wl=Wi, Cg=Cin, kh=kh, kw=kw, stride=stride,
-                        pad=pad, g_is_row=True, dst_sm=taps, dst_sn=Cin * taps, dst_stap=1)
+                        pad=pad, g_is_row=True, dst_sm=taps, dst_sn=Cin * taps, dst_stap=1, job=job)
     if need_db:
-        db = _colsum_bf16(g, B * Ho * Wo, Cout)
+        db = _colsum_bf16(g, B * Ho * Wo, Cout, defer=dfr)
     return dx, dw, db
 
 
@@ -289,14 +332,24 @@ def _stem_backward_bf16(col, weight, g, Cin, need_dw, need_db):
     _, _, kh, kw = weight.shape
     taps, Kp, P = kh * kw, col.shape[1], B * Ho * Wo
     dw = db = None
+    from . import functional as F_
+    dfr = (need_dw or need_db) and F_.can_defer(weight)
     if need_dw:
-        tmp = torch.empty((Kp, Cout), device=g.device, dtype=torch.float32)
-        _wgrad_bf16(col, g, tmp, B=1, Hs=1, Ws=P, Cp=Kp, Hl=1, Wl=P, Cg=Cout, kh=1, kw=1, stride=1, pad=0,
-                    g_is_row=False, dst_sm=Cout, dst_sn=1, dst_stap=0)
         dw = grad_like(weight)
-        _permute3(tmp, dw, (taps, Cin, Cout), (Cin * Cout, Cout, 1), (1, taps, Cin * taps))
+        if dfr:
+            # the pending reduction writes dw[co][c][tap] itself: row m = tap * Cin + c of the [Kp][Cout] product goes to
+            # tap + c * taps, column co to co * Cin * taps (what the permute launch below does otherwise)
+            job = L.ReduceJob()
+            _wgrad_bf16(col, g, dw, B=1, Hs=1, Ws=P, Cp=Kp, Hl=1, Wl=P, Cg=Cout, kh=1, kw=1, stride=1, pad=0,
+                        g_is_row=False, dst_sm=Cout, dst_sn=1, dst_stap=0, job=job)
+            job.mdiv, job.sm, job.smr, job.sn, job.Mvalid = Cin, 1, taps, Cin * taps, taps * Cin
+        else:
+            tmp = torch.empty((Kp, Cout), device=g.device, dtype=torch.float32)
+            _wgrad_bf16(col, g, tmp, B=1, Hs=1, Ws=P, Cp=Kp, Hl=1, Wl=P, Cg=Cout, kh=1, kw=1, stride=1, pad=0,
+                        g_is_row=False, dst_sm=Cout, dst_sn=1, dst_stap=0)
+            _permute3(tmp, dw, (taps, Cin, Cout), (Cin * Cout, Cout, 1), (1, taps, Cin * taps))
     if need_db:
-        db = _colsum_bf16(g, P, Cout)
+        db = _colsum_bf16(g, P, Cout, defer=dfr)
     return dw, db
 
 
@@ -385,11 +438,20 @@ class _ImageConvTBF16Fn(torch.autograd.Function):
                         Cout=Cin, kh=1, kw=1, stride=1, pad=0, transposed=False)
             dx = _nchw_view(dxh)
         if ctx.needs_input_grad[1]:
-            tmp = torch.empty((Cin, Kp), device=g.device, dtype=torch.float32)
-            _wgrad_bf16(xh, dcol, tmp, B=1, Hs=1, Ws=P, Cp=Cin, Hl=1, Wl=P, Cg=Kp, kh=1, kw=1, stride=1, pad=0,
-                        g_is_row=False, dst_sm=Kp, dst_sn=1, dst_stap=0)
+            from . import functional as F_
             dw = grad_like(weight)
-            _permute3(tmp, dw, (Cin, taps, Cout), (Kp, Cout, 1), (Cout * taps, 1, taps))
+            if F_.can_defer(weight):
+                # pending reduction with the column -> (tap, colour) map: column n = tap * Cout + c of the [Cin][Kp] product
+                # goes to tap + c * taps of dw[ci][c][tap]
+                job = L.ReduceJob()
+                _wgrad_bf16(xh, dcol, dw, B=1, Hs=1, Ws=P, Cp=Cin, Hl=1, Wl=P, Cg=Kp, kh=1, kw=1, stride=1, pad=0,
+                            g_is_row=False, dst_sm=Kp, dst_sn=1, dst_stap=0, job=job)
+                job.sm, job.ndiv, job.sn, job.snr, job.Nvalid = Cout * taps, Cout, 1, taps, taps * Cout
+            else:
+                tmp = torch.empty((Cin, Kp), device=g.device, dtype=torch.float32)
+                _wgrad_bf16(xh, dcol, tmp, B=1, Hs=1, Ws=P, Cp=Cin, Hl=1, Wl=P, Cg=Kp, kh=1, kw=1, stride=1, pad=0,
+                            g_is_row=False, dst_sm=Kp, dst_sn=1, dst_stap=0)
+                _permute3(tmp, dw, (Cin, taps, Cout), (Kp, Cout, 1), (Cout * taps, 1, taps))
         if has_bias and ctx.needs_input_grad[2]:
             db = _colsum(g, B * Ho * Wo, Cout)
         return dx, dw, db, None, None, None
@@ -479,6 +541,27 @@ def _gdn_backward_bf16(xh, norm, beta, gamma, g, inverse, beta_bound, gamma_boun
                         kh=1, kw=1, stride=1, pad=0, transposed=False,
                         epilogue=L.EPI_IGDN_BWD if inverse else L.EPI_GDN_BWD, aux=g, aux2=xh, aux3=norm)
     dbe = dge = db_conv = None
+    from . import functional as F_
+    if (need_dbeta or need_dgamma) and F_.can_defer(beta if need_dbeta else None, gamma if need_dgamma else None):
+        # pending reductions that end in the re-parametrisation's backward: d-beta, d-gamma (and the convolution's bias
+        # gradient) come out of the backward pass's one batched launch, no lic_gdn_reparam_bwd2 launch here
+        dbeta = dgamma = None
+        if bias_from_dx and need_dbeta and dxh is not None:
+            dbeta, db_conv = _colsum2_bf16(t, dxh, P, Cc, defer=True, reparam_a=(beta_c, beta_bound))
+        elif need_dbeta:
+            dbeta = _colsum_bf16(t, P, Cc, defer=True, reparam=(beta_c, beta_bound))
+        if dbeta is not None:
+            dbeta = dbeta.view(beta_c.shape)
+        if need_dgamma:
+            dgamma = torch.empty_like(gamma_c)
+            job = L.ReduceJob()
+            _wgrad_bf16(t, xh, dgamma, B=1, Hs=1, Ws=P, Cp=Cc, Hl=1, Wl=P, Cg=Cc, kh=1, kw=1, stride=1, pad=0,
+                        g_is_row=False, dst_sm=Cc, dst_sn=1, dst_stap=0, sq_g=1, job=job)
+            _reparam_epilogue(job, gamma_c, gamma_bound)
+            F_._PENDING_KEEP.append(gamma_c)
+        if bias_from_dx:
+            return dxh, dbeta, dgamma, db_conv
+        return dxh, dbeta, dgamma
     if bias_from_dx and need_dbeta and dxh is not None:
         dbe, db_conv = _colsum2_bf16(t, dxh, P, Cc)
     elif need_dbeta:

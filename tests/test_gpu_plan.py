@@ -179,3 +179,51 @@ def test_trainer_with_step_plan_trains_like_the_eager_trainer(tmp_path):
     la = [(t, v, s) for t, v, s in rows_a if t.startswith("losses/")]
     lb = [(t, v, s) for t, v, s in rows_b if t.startswith("losses/")]
     assert la == lb and len(la) == 4 * 8   # (the loss itself is a tensor: the eight plain numbers per step)
+
+
+def test_deferred_reductions_change_no_bit():
+    """the end-of-backward batched reduction (functional.can_defer / lic_reduce_batch) against the launch-by-launch
+    reductions: every gradient of a bf16 model step bit for bit -- first gradients, gradients accumulated onto existing ones
+    (no deferral there), and a convolution applied twice in one graph (flush before the second use)"""
+    _need_gpu()
+    import neural_image_compression_amd as nic
+    from neural_image_compression_amd import functional as F_
+    from neural_image_compression_amd import functional_bf16 as FB
+    dev = torch.device("cuda:0")
+    torch.manual_seed(4)
+    m = nic.JointAutoregressiveHierarchical(128, 3).to(dev)
+    m.set_precision("bf16")
+    x = torch.rand(2, 3, 128, 128, device=dev).contiguous(memory_format=torch.channels_last)
+    noise = (torch.rand(2, 128, 2, 2, device=dev), torch.rand(2, 128, 8, 8, device=dev))
+
+    def grads(defer, passes):
+        F_.DEFER_REDUCTIONS = defer
+        for p in m.parameters():
+            p.grad = None
+        for _ in range(passes):
+            nic.rd_loss(m(x, noise=noise), x, 0.01, sync=False)["loss"].backward()
+        torch.cuda.synchronize()
+        return [p.grad.clone() for p in m.parameters()]
+
+    try:
+        for passes in (1, 2):
+            ga, gb = grads(True, passes), grads(False, passes)
+            for (n, _), a, b in zip(m.named_parameters(), ga, gb):
+                assert torch.equal(a, b), (passes, n, float((a - b).abs().max()))
+        assert not F_._PENDING_JOBS and not F_._PENDING_KEEP
+        # one weight, two uses
+        w = (torch.randn(128, 128, 3, 3, device=dev) * 0.05).requires_grad_(True)
+        b = torch.zeros(128, device=dev, requires_grad=True)
+        xin = torch.randn(2, 128, 16, 16, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+
+        def twice(defer):
+            F_.DEFER_REDUCTIONS = defer
+            w.grad = b.grad = None
+            y = FB.conv2d_bf16(FB.conv2d_bf16(xin, w, b, 1, 1), w, b, 1, 1, out_f32=True)
+            y.square().mean().backward()
+            torch.cuda.synchronize()
+            return w.grad.clone(), b.grad.clone()
+        (wa, ba), (wb, bb) = twice(True), twice(False)
+        assert torch.equal(wa, wb) and torch.equal(ba, bb)
+    finally:
+        F_.DEFER_REDUCTIONS = True
