@@ -52,8 +52,9 @@ CONFIGS = {
     "4": ("jah", 192, 3, 32, 256, 256, 0.01),
     "5": ("jah", 192, 3, 16, 512, 512, 0.01),
     "hmr": ("hmr", 192, 3, 32, 256, 256, 0.01),  # the 3x3 residual model, for the record
+    "hmrh": ("hmr", 192, 3, 32, 256, 256, 0.01),  # ... in bf16 storage
 }
-BF16_CONFIGS = ("3", "2h")
+BF16_CONFIGS = ("3", "2h", "hmrh")
 BF16_MFMA_PEAK_TF = 2500.0
 
 
@@ -229,7 +230,7 @@ def main():
     plan = None
     if use_plan:
         from neural_image_compression_amd.plan import StepPlan
-        plan = StepPlan(model, nic.rd_loss, lam, x)
+        plan = StepPlan(model, nic.rd_loss, lam, x, tune=os.environ.get("LIC_PLAN_TUNE") == "1")
 
         def step():
             _, res = plan.step(x)

@@ -34,6 +34,11 @@ def _as_bf16_nhwc(t: torch.Tensor) -> torch.Tensor:
     return th if th.dtype == BF16 else th.to(BF16)
 
 
+def as_bf16(t: torch.Tensor) -> torch.Tensor:
+    """the bf16 view of an activation the bf16 layers hand around (NHWC memory, NCHW-logical)"""
+    return t if t.dtype == BF16 else t.to(BF16)
+
+
 def _pack_bf16(src: torch.Tensor, taps, K, N, s_tap, s_k, s_n, kperm=False) -> torch.Tensor:
     lib = L.load()
     out = torch.empty((lib.lic_packed_weight_bf16_elems(taps, K, N),), device=src.device, dtype=BF16)

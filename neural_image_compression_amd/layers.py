@@ -35,9 +35,9 @@ class Conv2d(nn.Conv2d):
             if residual is not None:
                 raise NotImplementedError("bf16 mode covers the 5x5 conv/GDN stacks and the latent-side layers")
             if self.in_channels < 4:
-                if leaky:
-                    raise NotImplementedError
-                return FB_.image_conv2d_bf16(x, self.weight, self.bias, s, p)
+                y = FB_.image_conv2d_bf16(x, self.weight, self.bias, s, p)
+                # (the 3x3 model's first block: the activation of an RGB layer is an element-wise launch of its own)
+                return torch.nn.functional.leaky_relu(y, slope) if leaky else y
             return FB_.conv2d_bf16(x, self.weight, self.bias, s, p, out_f32, leaky, slope, 0, out)
         if self.in_channels < 4:  # RGB stem: im2col + dense MFMA GEMM
             y = F_.image_conv2d(x, self.weight, self.bias, s, p, leaky, slope)
@@ -107,6 +107,15 @@ def run_bf16(seq: nn.Sequential, x: Tensor, out_f32: bool = True, out=None) -> T
             else:
                 x = m(x, bf16=True, out_f32=(out_f32 and i == len(mods) - 1))
         elif isinstance(m, GDN):
+            x = m(x, bf16=True)
+        elif isinstance(m, TransposedDeconv3x3):
+            last = out_f32 and i == len(mods) - 1
+            if isinstance(nxt, LeakyReLU):
+                x = m.deconv(x, bf16=True, leaky=True, slope=nxt.negative_slope)
+                i += 2
+                continue
+            x = m.deconv(x, bf16=True, out_f32=last) if m.deconv.out_channels >= 4 else m.deconv(x, bf16=True)
+        elif isinstance(m, (ResidualBlock, ResidualBlockWithStride, ResidualBlockUpsample)):
             x = m(x, bf16=True)
         else:
             raise NotImplementedError(f"bf16 mode does not cover {type(m).__name__}")
@@ -204,6 +213,15 @@ class GDN(nn.Module):
                       self.gamma_reparam.bound_value, self.beta_reparam.pedestal_value, residual)
 
 
+def _conv_gdn_bf16(conv, g: "GDN", x: Tensor) -> Tensor:
+    """conv -> GDN / IGDN of a residual block in bf16 storage: one launch where the fused kernel covers the pair"""
+    if FUSE_CONV_GDN and x.dim() == 4 and FB_.fused_gdn_supported_bf16(max(conv.in_channels, 8), conv.out_channels):
+        return FB_.conv_gdn_bf16(x, conv.weight, conv.bias, g.beta, g.gamma, _pair(conv.stride), _pair(conv.padding),
+                                 g.inverse, g.beta_reparam.bound_value, g.gamma_reparam.bound_value,
+                                 g.beta_reparam.pedestal_value)
+    return g(conv(x, bf16=True), bf16=True)
+
+
 # ---- residual blocks (Layers.py:18-119) --------------------------------------------------------
 class TransposedDeconv3x3(nn.Module):
     def __init__(self, in_ch, out_ch, upsample=2):
@@ -224,7 +242,12 @@ class ResidualBlockWithStride(nn.Module):
         self.gdn = GDN(out_ch, beta_min=1e-6, gamma_init=.1)
         self.skip = Conv2d(in_ch, out_ch, kernel_size=1, stride=stride) if (stride != 1 or in_ch != out_ch) else None
 
-    def forward(self, x: Tensor) -> Tensor:
+    def forward(self, x: Tensor, bf16: bool = False) -> Tensor:
+        if bf16:   # bf16 storage: the same graph, the skip connection as a bf16 add behind the (fused) conv + GDN
+            out = self.conv1(x, bf16=True, leaky=True, slope=self.leaky_relu.negative_slope)
+            out = _conv_gdn_bf16(self.conv2, self.gdn, out)
+            identity = FB_.as_bf16(x) if self.skip is None else self.skip(x, bf16=True)
+            return out + identity
         out = self.conv1(x, leaky=True, slope=self.leaky_relu.negative_slope)
         out = self.conv2(out)
         identity = x if self.skip is None else self.skip(x)
@@ -240,7 +263,11 @@ class ResidualBlockUpsample(nn.Module):
         self.igdn = GDN(out_ch, inverse=True, beta_min=1e-6, gamma_init=.1)
         self.upsample = TransposedDeconv3x3(in_ch, out_ch, upsample)
 
-    def forward(self, x: Tensor) -> Tensor:
+    def forward(self, x: Tensor, bf16: bool = False) -> Tensor:
+        if bf16:
+            out = self.subpel_conv.deconv(x, bf16=True, leaky=True, slope=self.leaky_relu.negative_slope)
+            out = _conv_gdn_bf16(self.conv, self.igdn, out)
+            return out + self.upsample.deconv(x, bf16=True)
         out = self.subpel_conv(x, leaky=True, slope=self.leaky_relu.negative_slope)
         out = self.conv(out)
         identity = self.upsample(x)
@@ -255,8 +282,11 @@ class ResidualBlock(nn.Module):
         self.conv2 = Conv2d(out_ch, out_ch, kernel_size=3, stride=1, padding=1)
         self.skip = Conv2d(in_ch, out_ch, kernel_size=1, stride=1) if in_ch != out_ch else None
 
-    def forward(self, x: Tensor) -> Tensor:
+    def forward(self, x: Tensor, bf16: bool = False) -> Tensor:
         s = self.leaky_relu.negative_slope
+        if bf16:
+            out = self.conv2(self.conv1(x, bf16=True, leaky=True, slope=s), bf16=True, leaky=True, slope=s)
+            return out + (FB_.as_bf16(x) if self.skip is None else self.skip(x, bf16=True))
         out = self.conv1(x, leaky=True, slope=s)
         identity = x if self.skip is None else self.skip(x)
         return self.conv2(out, leaky=True, slope=s, residual=identity)  # leaky(conv2) + identity

@@ -49,8 +49,6 @@ class _HyperpriorContextModel(nn.Module):
         for v in (precision, latent):
             if v not in ("fp32", "bf16"):
                 raise ValueError(f"precision must be 'fp32' or 'bf16', got {v!r}")
-        if "bf16" in (precision, latent) and not isinstance(self.encoder, Encoder5x5):
-            raise NotImplementedError("bf16 mode covers the 5x5 model (JointAutoregressiveHierarchical)")
         self.encoder.precision = self.decoder.precision = precision
         for m in (self.hyper_encoder, self.hyper_decoder, self.context_model, self.entropy_parameters):
             m.precision = latent

@@ -58,6 +58,10 @@ class StepPlan:
         self.noise = (self.u[:nz].view(Bn, hz, wz, Mz).permute(0, 3, 1, 2),
                       self.u[nz:].view(Bn, hy, wy, Mc).permute(0, 3, 1, 2))
         del probe, y, z
+        # the second stream: the model's own (high priority: the decoder chain it carries is the critical path of the
+        # overlapped region -- the plan's second stream inherits the capture's fork, so it carries that chain too)
+        if side_stream is None and hasattr(model, "side_stream"):
+            side_stream = model.side_stream()
         self.side = side_stream if side_stream is not None else torch.cuda.Stream(device=dev)
         self.side2 = torch.cuda.Stream(device=dev)
         self._sides = (C.c_void_p * 2)(self.side.cuda_stream, self.side2.cuda_stream)
