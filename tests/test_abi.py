@@ -115,12 +115,12 @@ def test_check_raises_with_status_name(lib):
 
 
 def test_descriptor_structs_have_the_c_layout(lib, tmp_path):
-    """the ctypes mirrors of lic_igemm_desc / lic_wgrad_desc / lic_prep_job are as large as the C structs"""
+    """the ctypes mirrors of lic_igemm_desc / lic_wgrad_desc / lic_prep_job / lic_adam_job / lic_reduce_job are as large as the C structs"""
     src = tmp_path / "sz.c"
     src.write_text('#include <stdio.h>\n#include "lic.h"\nint main(void){printf("%zu %zu %zu\\n", sizeof(lic_igemm_desc), '
-                   'sizeof(lic_wgrad_desc), sizeof(lic_prep_job));printf("%zu\\n", sizeof(lic_adam_job));return 0;}\n')
+                   'sizeof(lic_wgrad_desc), sizeof(lic_prep_job));printf("%zu %zu\\n", sizeof(lic_adam_job), sizeof(lic_reduce_job));return 0;}\n')
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     c_sizes = [int(v) for v in subprocess.check_output([str(exe)], text=True).split()]
     assert c_sizes == [ctypes.sizeof(lib.IgemmDesc), ctypes.sizeof(lib.WgradDesc), ctypes.sizeof(lib.PrepJob),
-                       ctypes.sizeof(lib.AdamJob)]
+                       ctypes.sizeof(lib.AdamJob), ctypes.sizeof(lib.ReduceJob)]
