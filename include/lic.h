@@ -475,8 +475,8 @@ int lic_adam_run(const lic_adam_job* jobs_device, int32_t njobs, int64_t total_b
 /* ------------------------------------------------------------------------------------------
  * lic_reduce_batch -- every pending reduction of a backward pass (Trainer.py:84 `loss.backward()`) in ONE launch.
  *   The weight-gradient launches end in a slab reduction and the column sums (bias / GDN beta gradients) in a second
- *   stage: 41 launches of 5-15 us per config-3 step.  lic_wgrad_bf16_partial / lic_colsum_bf16_partial /
- *   lic_colsum2_bf16_partial launch the first stage only and fill a lic_reduce_job; lic_reduce_batch(jobs, n) -- `jobs` a
+ *   stage: 41 launches of 5-15 us per config-3 step.  lic_wgrad_partial / lic_colsum_partial (fp32 operands),
+ *   lic_wgrad_bf16_partial / lic_colsum_bf16_partial / lic_colsum2_bf16_partial launch the first stage only and fill a lic_reduce_job; lic_reduce_batch(jobs, n) -- `jobs` a
  *   HOST array, copied into the kernel arguments, LIC_REDUCE_MAX_JOBS per launch -- finishes them with the arithmetic
  *   and association order of the stand-alone second stages (bitwise the same results), optionally followed per element
  *   by the GDN re-parametrisation's backward (epilogue LIC_REDUCE_EPI_REPARAM: lic_gdn_reparam_bwd with `param`, `bound`
@@ -498,6 +498,10 @@ typedef struct lic_reduce_job {
   float scale, bound;
   int32_t block0, nblocks;
 } lic_reduce_job;
+int lic_wgrad_partial(const lic_wgrad_desc* d, void* workspace, size_t workspace_bytes, lic_reduce_job* job,
+                      lic_stream_t stream);      /* fp32 operands (lic_wgrad's first stage) */
+int lic_colsum_partial(const float* in, int64_t ld, int64_t P, int32_t C, float scale, float* out, void* workspace,
+                       size_t workspace_bytes, lic_reduce_job* job, lic_stream_t stream);
 int lic_wgrad_bf16_partial(const lic_wgrad_desc* d, void* workspace, size_t workspace_bytes, lic_reduce_job* job,
                            lic_stream_t stream);
 int lic_colsum_bf16_partial(const void* in, int64_t ld, int64_t P, int32_t C, float scale, float* out, void* workspace,

@@ -215,6 +215,28 @@ LIC_EXPORT size_t lic_colsum_workspace_bytes(int64_t P, int32_t C) {
   if (P <= 0 || C <= 0) return 0;
   return (size_t)colsum_chunks(P) * C * sizeof(float);
 }
+// stage 1 only; `job` receives stage 2 for a later lic_reduce_batch
+LIC_EXPORT int lic_colsum_partial(const float* in, int64_t ld, int64_t P, int32_t C, float scale, float* out,
+                                  void* workspace, size_t workspace_bytes, lic_reduce_job* job, lic_stream_t stream) {
+  if (!in || !out || !workspace || !job || P <= 0 || C <= 0) return LIC_ERR_INVALID;
+  const int nchunk = colsum_chunks(P);
+  if (workspace_bytes < (size_t)nchunk * C * sizeof(float)) return LIC_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  const int vec = (C % 4 == 0) && (ld % 4 == 0) && al16(in);
+  if (C == 3 && ld == 3 && al16(in))
+    hipLaunchKernelGGL(colsum3_stage1, dim3(nchunk), dim3(256), 0, s, in, (long)P, (float*)workspace, nchunk);
+  else
+    hipLaunchKernelGGL(colsum_stage1, dim3((C + 63) / 64, nchunk), dim3(256), 0, s, in, (long)ld, (long)P, C,
+                       (float*)workspace, nchunk, vec);
+  *job = lic_reduce_job{};
+  job->src = (const float*)workspace;
+  job->dst = out;
+  job->kind = LIC_REDUCE_COLUMNS;
+  job->splitk = nchunk;
+  job->Cn = C;
+  job->scale = scale;
+  return lic_check_launch();
+}
 LIC_EXPORT int lic_colsum(const float* in, int64_t ld, int64_t P, int32_t C, float scale, float* out,
                           void* workspace, size_t workspace_bytes, lic_stream_t stream) {
   if (!in || !out || !workspace || P <= 0 || C <= 0) return LIC_ERR_INVALID;

@@ -1817,6 +1817,31 @@ LIC_EXPORT int lic_wgrad_stage(const lic_wgrad_desc* d, void* workspace, size_t 
   if (stage < 0 || stage > 2) return LIC_ERR_INVALID;
   return wgrad_run(d, workspace, workspace_bytes, stage, stream);
 }
+// the MFMA launch only; `job` receives the slab reduction for a later lic_reduce_batch (the workspace must live until then)
+LIC_EXPORT int lic_wgrad_partial(const lic_wgrad_desc* d, void* workspace, size_t workspace_bytes, lic_reduce_job* job,
+                                 lic_stream_t stream) {
+  if (!job) return LIC_ERR_INVALID;
+  WgPlan pl;
+  int rc = wg_plan(d, &pl);
+  if (rc != LIC_OK) return rc;
+  rc = wgrad_run(d, workspace, workspace_bytes, 1, stream);
+  if (rc != LIC_OK) return rc;
+  *job = lic_reduce_job{};
+  job->src = (const float*)workspace;
+  job->dst = d->dst;
+  job->kind = LIC_REDUCE_SLABS;
+  job->splitk = pl.splitk;
+  job->ntaps = pl.ntaps;
+  job->Cm = pl.Cm;
+  job->Cn = pl.Cn;
+  job->Mvalid = pl.Cm;
+  job->Nvalid = pl.Cn;
+  job->sm = d->dst_sm;
+  job->sn = d->dst_sn;
+  job->stap = d->dst_stap;
+  job->scale = d->scale;
+  return LIC_OK;
+}
 LIC_EXPORT int lic_wgrad_kernel_name(const lic_wgrad_desc* d, char* buf, size_t n) {
   WgPlan pl;
   const int rc = wg_plan(d, &pl);

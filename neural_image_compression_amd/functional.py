@@ -61,6 +61,9 @@ def _ptr(t: Optional[torch.Tensor]):
 # reductions left pending until the end of a backward pass (lic_reduce_batch, include/lic.h)
 # ------------------------------------------------------------------------------------------
 DEFER_REDUCTIONS = os.environ.get("LIC_DEFER_REDUCTIONS", "1") != "0"
+# ... of the fp32 path too?  Off: its slab reductions are bandwidth-sized (60-240 MB each at config 2) and ran beside
+# the other stream's kernels; batched at the end of backward they sit on the critical path (1412 vs 1431 img/s, same box)
+DEFER_FP32 = os.environ.get("LIC_DEFER_FP32", "0") == "1"
 _PENDING_JOBS = []   # L.ReduceJob of the running backward pass
 _PENDING_KEEP = []   # tensors they name: partial sums, outputs, parameters
 _PENDING_SEEN = set()
@@ -238,7 +241,9 @@ def _timed(name, flops, act_bytes, launch):
 
 
 def _wgrad(p, g, dst, *, B, Hs, Ws, Cp, Hl, Wl, Cg, kh, kw, stride, pad, g_is_row, dst_sm, dst_sn,
-           dst_stap, sq_p=0, sq_g=0, scale=1.0):
+           dst_stap, sq_p=0, sq_g=0, scale=1.0, job=None):
+    """`job` (an L.ReduceJob): launch the MFMA kernel only and leave the slab reduction pending (`defer`; the caller may
+    still set the job's epilogue / index-map fields); None: reduce right away"""
     d = L.WgradDesc()
     d.p, d.g, d.dst = _ptr(p), _ptr(g), _ptr(dst)
     d.p_ld, d.g_ld = Cp, Cg
@@ -253,7 +258,21 @@ def _wgrad(p, g, dst, *, B, Hs, Ws, Cp, Hl, Wl, Cg, kh, kw, stride, pad, g_is_ro
         KERNEL_TRACE.add(_kernel_name(lib.lic_wgrad_kernel_name, d))
     nbytes = lib.lic_wgrad_workspace_bytes(C.byref(d))
     ws = torch.empty((max(nbytes, 4) + 3) // 4, device=p.device, dtype=torch.float32)
-    if PROFILE is None or 2.0 * B * Hs * Ws * kh * kw * Cp * Cg < PROFILE_MIN_FLOP:
+    timed = not (PROFILE is None or 2.0 * B * Hs * Ws * kh * kw * Cp * Cg < PROFILE_MIN_FLOP)
+    if job is not None:
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        L.check(lib.lic_wgrad_partial(C.byref(d), _ptr(ws), nbytes, C.byref(job), _stream()), "lic_wgrad_partial")
+        defer(job, ws, p, g)   # (not `dst`: autograd adopts a gradient tensor only if nobody else holds it)
+        if timed:
+            e1.record()
+            nm = C.create_string_buffer(96)
+            lib.lic_wgrad_kernel_name(C.byref(d), nm, 96)
+            PROFILE.append((nm.value.decode(), 2 * B * Hs * Ws * kh * kw * Cp * Cg,
+                            4 * (B * Hs * Ws * Cp + B * Hl * Wl * Cg), e0, e1))
+        return
+    if not timed:
         L.check(lib.lic_wgrad(C.byref(d), _ptr(ws), nbytes, _stream()), "lic_wgrad")
         return
     nm = C.create_string_buffer(96)
@@ -267,11 +286,21 @@ def _wgrad(p, g, dst, *, B, Hs, Ws, Cp, Hl, Wl, Cg, kh, kw, stride, pad, g_is_ro
     PROFILE.append((nm.value.decode(), flops, 4 * (B * Hs * Ws * Cp + B * Hl * Wl * Cg), e0, e1))
 
 
-def _colsum(t2d: torch.Tensor, P: int, Cc: int, scale: float = 1.0) -> torch.Tensor:
+def _colsum(t2d: torch.Tensor, P: int, Cc: int, scale: float = 1.0, deferred: bool = False, reparam=None) -> torch.Tensor:
+    """column sums; `deferred`: the second stage joins the backward pass's batched reduction (`defer`), optionally
+    followed by the GDN re-parametrisation's backward (`reparam` = (parameter, bound))"""
     lib = L.load()
     nbytes = lib.lic_colsum_workspace_bytes(P, Cc)
     ws = torch.empty((nbytes + 3) // 4, device=t2d.device, dtype=torch.float32)
     out = torch.empty((Cc,), device=t2d.device, dtype=torch.float32)
+    if deferred:
+        job = L.ReduceJob()
+        L.check(lib.lic_colsum_partial(_ptr(t2d), Cc, P, Cc, scale, _ptr(out), _ptr(ws), nbytes, C.byref(job), _stream()),
+                "lic_colsum_partial")
+        if reparam is not None:
+            job.epilogue, job.param, job.bound = L.REDUCE_EPI_REPARAM, reparam[0].data_ptr(), reparam[1]
+        defer(job, ws, t2d, reparam[0] if reparam is not None else None)
+        return out
     L.check(lib.lic_colsum(_ptr(t2d), Cc, P, Cc, scale, _ptr(out), _ptr(ws), nbytes, _stream()),
             "lic_colsum")
     return out
@@ -393,26 +422,30 @@ def _conv_backward(xh, weight, g, stride, pad, transposed, tap_mask, need_dx, ne
         _igemm(g, wp, dxh, B=B, Hi=Ho, Wi=Wo, Cin=Cout, Ho=Hi, Wo=Wi, Cout=Cin, kh=kh, kw=kw,
                stride=stride, pad=pad, transposed=not transposed, tap_mask=tap_mask)
         dx = _nchw_view(dxh)
+    # the slab reduction of the weight gradient and the second stage of the bias sum wait for the end of the backward
+    # pass when nothing can read these gradients earlier (can_defer): one batched launch for the whole pass
+    dfr = DEFER_FP32 and (need_dw or need_db) and can_defer(weight)
     if need_dw:
         dw = grad_like(weight)
         taps = kh * kw
+        job = L.ReduceJob() if dfr else None
         if transposed:  # weight [Cin,Cout,kh,kw]; small grid = input, gathered = grad
             _wgrad(xh, g, dw, B=B, Hs=Hi, Ws=Wi, Cp=Cin, Hl=Ho, Wl=Wo, Cg=Cout, kh=kh, kw=kw,
-                   stride=stride, pad=pad, g_is_row=False, dst_sm=Cout * taps, dst_sn=taps, dst_stap=1)
+                   stride=stride, pad=pad, g_is_row=False, dst_sm=Cout * taps, dst_sn=taps, dst_stap=1, job=job)
         else:  # weight [Cout,Cin,kh,kw]; small grid = output grad, gathered = input
             _wgrad(g, xh, dw, B=B, Hs=Ho, Ws=Wo, Cp=Cout, Hl=Hi, Wl=Wi, Cg=Cin, kh=kh, kw=kw,
-                   stride=stride, pad=pad, g_is_row=True, dst_sm=taps, dst_sn=Cin * taps, dst_stap=1)
+                   stride=stride, pad=pad, g_is_row=True, dst_sm=taps, dst_sn=Cin * taps, dst_stap=1, job=job)
     if need_db:
-        db = _bias_grad(g, B * Ho * Wo, Cout)
+        db = _bias_grad(g, B * Ho * Wo, Cout, dfr)
     return dx, dw, db
 
 
-def _bias_grad(g, P, Cout):
+def _bias_grad(g, P, Cout, deferred=False):
     """column sums of the output gradient; from the GDN backward's per-workgroup partials when it left them"""
     part = getattr(g, "_lic_colsum_partial", None)
     if part is not None and part.shape[1] == Cout:
-        return _colsum(part, part.shape[0], Cout)
-    return _colsum(g, P, Cout)
+        return _colsum(part, part.shape[0], Cout, deferred=deferred)
+    return _colsum(g, P, Cout, deferred=deferred)
 
 
 def conv2d(x, weight, bias, stride=1, padding=0, leaky=False, slope=0.01, tap_mask=0, residual=None, out=None):
@@ -525,14 +558,23 @@ def _image_conv_backward(col, weight, g, stride, pad, in_shape, need_dx, need_dw
         L.check(lib.lic_col2im(_ptr(dcol), None, _ptr(dxh), B, Ho, Wo, Cin, Hi, Wi, kh, kw, stride,
                                pad, Kp, _stream()), "lic_col2im")
         dx = _nchw_view(dxh)
+    dfr = DEFER_FP32 and (need_dw or need_db) and can_defer(weight)
     if need_dw:
-        tmp = torch.empty((Kp, Cout), device=g.device, dtype=torch.float32)
-        _wgrad(col, g, tmp, B=1, Hs=1, Ws=P, Cp=Kp, Hl=1, Wl=P, Cg=Cout, kh=1, kw=1, stride=1, pad=0,
-               g_is_row=False, dst_sm=Cout, dst_sn=1, dst_stap=0)
         dw = grad_like(weight)
-        _permute3(tmp, dw, (taps, Cin, Cout), (Cin * Cout, Cout, 1), (1, taps, Cin * taps))
+        if dfr:
+            # the pending reduction writes dw[co][c][tap] itself: row m = tap * Cin + c of the [Kp][Cout] product goes to
+            # tap + c * taps, column co to co * Cin * taps (what the permute launch below does otherwise)
+            job = L.ReduceJob()
+            _wgrad(col, g, dw, B=1, Hs=1, Ws=P, Cp=Kp, Hl=1, Wl=P, Cg=Cout, kh=1, kw=1, stride=1, pad=0,
+                   g_is_row=False, dst_sm=Cout, dst_sn=1, dst_stap=0, job=job)
+            job.mdiv, job.sm, job.smr, job.sn, job.Mvalid = Cin, 1, taps, Cin * taps, taps * Cin
+        else:
+            tmp = torch.empty((Kp, Cout), device=g.device, dtype=torch.float32)
+            _wgrad(col, g, tmp, B=1, Hs=1, Ws=P, Cp=Kp, Hl=1, Wl=P, Cg=Cout, kh=1, kw=1, stride=1, pad=0,
+                   g_is_row=False, dst_sm=Cout, dst_sn=1, dst_stap=0)
+            _permute3(tmp, dw, (taps, Cin, Cout), (Cin * Cout, Cout, 1), (1, taps, Cin * taps))
     if need_db:
-        db = _bias_grad(g, P, Cout)
+        db = _bias_grad(g, P, Cout, dfr)
     return dx, dw, db
 
 
@@ -657,16 +699,25 @@ class _ImageConvTFn(torch.autograd.Function):
             _igemm(dcol, wpk, dxh, B=1, Hi=1, Wi=P, Cin=Kp, Ho=1, Wo=P, Cout=Cin, kh=1, kw=1, stride=1,
                    pad=0, transposed=False)
             dx = _nchw_view(dxh)
+        dfr = DEFER_FP32 and (ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2])) and can_defer(weight)
         if ctx.needs_input_grad[1]:
-            tmp = torch.empty((Cin, Kp), device=g.device, dtype=torch.float32)
+            dw = grad_like(weight)
             # rows = the 80 columns of dcol, cols = the Cin channels of x: ONE 128x192 tile spans the whole product,
             # so each operand is streamed once per split (x on the rows needed 3 x 2 tiles of 64x64: 378 -> ~200 us)
-            _wgrad(xh, dcol, tmp, B=1, Hs=1, Ws=P, Cp=Cin, Hl=1, Wl=P, Cg=Kp, kh=1, kw=1, stride=1, pad=0,
-                   g_is_row=True, dst_sm=1, dst_sn=Kp, dst_stap=0)
-            dw = grad_like(weight)
-            _permute3(tmp, dw, (Cin, taps, Cout), (Kp, Cout, 1), (Cout * taps, 1, taps))
+            if dfr:
+                # pending reduction with the column -> (tap, colour) map: row m = tap * Cout + c of the [Kp][Cin] product
+                # (g_is_row: rows = dcol's columns) goes to tap + c * taps of dw[ci][c][tap], column ci to ci * Cout * taps
+                job = L.ReduceJob()
+                _wgrad(xh, dcol, dw, B=1, Hs=1, Ws=P, Cp=Cin, Hl=1, Wl=P, Cg=Kp, kh=1, kw=1, stride=1, pad=0,
+                       g_is_row=True, dst_sm=1, dst_sn=Kp, dst_stap=0, job=job)
+                job.mdiv, job.sm, job.smr, job.sn, job.Mvalid = Cout, 1, taps, Cout * taps, taps * Cout
+            else:
+                tmp = torch.empty((Cin, Kp), device=g.device, dtype=torch.float32)
+                _wgrad(xh, dcol, tmp, B=1, Hs=1, Ws=P, Cp=Cin, Hl=1, Wl=P, Cg=Kp, kh=1, kw=1, stride=1, pad=0,
+                       g_is_row=True, dst_sm=1, dst_sn=Kp, dst_stap=0)
+                _permute3(tmp, dw, (Cin, taps, Cout), (Kp, Cout, 1), (Cout * taps, 1, taps))
         if has_bias and ctx.needs_input_grad[2]:
-            db = _colsum(g, B * Ho * Wo, Cout)
+            db = _colsum(g, B * Ho * Wo, Cout, deferred=dfr)
         return dx, dw, db, None, None, None
 
 
@@ -794,6 +845,10 @@ def _gdn_backward(xh, norm, beta, gamma, g, inverse, beta_bound, gamma_bound, pe
     dbe = None
     beta_c, gamma_c = beta.contiguous(), gamma.contiguous()
     gp = _gdn_gamma_packed(gamma, gamma_bound, pedestal) if need_dx else None
+    # the parameter-gradient reductions (and the re-parametrisation behind them) may wait for the end of the pass
+    dfr = DEFER_FP32 and (need_dbeta or need_dgamma) and \
+        can_defer(beta if need_dbeta else None, gamma if need_dgamma else None)
+    dbeta_d = None
     if need_dx and lib.lic_gdn_supported(Cc):
         # the dedicated one-sweep kernel: t built from (g, x, norm) as the tile is loaded; it also emits
         # per-workgroup column sums of t (-> d beta) and of dx (-> the d bias of the conv in front)
@@ -807,7 +862,10 @@ def _gdn_backward(xh, norm, beta, gamma, g, inverse, beta_bound, gamma_bound, pe
                lambda: L.check(lib.lic_gdn_bwd(_ptr(g), _ptr(xh), _ptr(norm), _ptr(gp), _ptr(dxh), _ptr(t), _ptr(pt),
                                                _ptr(pdx), P, Cc, int(inverse), _stream()), "lic_gdn_bwd"))
         if need_dbeta:
-            dbe = _colsum(pt, rows, Cc)
+            if dfr:   # pending: second stage + re-parametrisation in the pass's batched reduction
+                dbeta_d = _colsum(pt, rows, Cc, deferred=True, reparam=(beta_c, beta_bound)).view(beta_c.shape)
+            else:
+                dbe = _colsum(pt, rows, Cc)
         cs_dx = pdx
     elif need_dx and Cc % 4 == 0:
         # one launch: t = dL/dnorm built on the fly as the contraction's operand (and stored for the
@@ -825,6 +883,21 @@ def _gdn_backward(xh, norm, beta, gamma, g, inverse, beta_bound, gamma_bound, pe
                    stride=1, pad=0, transposed=False, epilogue=L.EPI_IGDN_BWD if inverse else L.EPI_GDN_BWD,
                    aux=g, aux2=xh, aux3=norm)
     dge = None
+    if dfr:
+        # pending reductions that end in the re-parametrisation's backward: no lic_gdn_reparam_bwd2 launch here
+        dbeta, dgamma = dbeta_d, None
+        if need_dbeta and dbeta is None:
+            dbeta = _colsum(t, P, Cc, deferred=True, reparam=(beta_c, beta_bound)).view(beta_c.shape)
+        if need_dgamma:
+            dgamma = torch.empty_like(gamma_c)
+            job = L.ReduceJob()
+            _wgrad(t, xh, dgamma, B=1, Hs=1, Ws=P, Cp=Cc, Hl=1, Wl=P, Cg=Cc, kh=1, kw=1, stride=1, pad=0,
+                   g_is_row=False, dst_sm=Cc, dst_sn=1, dst_stap=0, sq_g=1, job=job)
+            job.epilogue, job.param, job.bound = L.REDUCE_EPI_REPARAM, gamma_c.data_ptr(), gamma_bound
+            _PENDING_KEEP.append(gamma_c)
+        if cs_dx is not None and dxh is not None:
+            dxh._lic_colsum_partial = cs_dx
+        return dxh, dbeta, dgamma
     if need_dbeta and dbe is None:
         dbe = _colsum(t, P, Cc)
     if need_dgamma:

@@ -181,7 +181,8 @@ def test_trainer_with_step_plan_trains_like_the_eager_trainer(tmp_path):
     assert la == lb and len(la) == 4 * 8   # (the loss itself is a tensor: the eight plain numbers per step)
 
 
-def test_deferred_reductions_change_no_bit():
+@pytest.mark.parametrize("precision,M,K", [("bf16", 128, 3), ("fp32", 64, 1), ("fp32", 192, 3)])
+def test_deferred_reductions_change_no_bit(precision, M, K):
     """the end-of-backward batched reduction (functional.can_defer / lic_reduce_batch) against the launch-by-launch
     reductions: every gradient of a bf16 model step bit for bit -- first gradients, gradients accumulated onto existing ones
     (no deferral there), and a convolution applied twice in one graph (flush before the second use)"""
@@ -191,13 +192,14 @@ def test_deferred_reductions_change_no_bit():
     from neural_image_compression_amd import functional_bf16 as FB
     dev = torch.device("cuda:0")
     torch.manual_seed(4)
-    m = nic.JointAutoregressiveHierarchical(128, 3).to(dev)
-    m.set_precision("bf16")
+    m = nic.JointAutoregressiveHierarchical(M, K).to(dev)
+    m.set_precision(precision)
     x = torch.rand(2, 3, 128, 128, device=dev).contiguous(memory_format=torch.channels_last)
-    noise = (torch.rand(2, 128, 2, 2, device=dev), torch.rand(2, 128, 8, 8, device=dev))
+    noise = (torch.rand(2, M, 2, 2, device=dev), torch.rand(2, M, 8, 8, device=dev))
 
     def grads(defer, passes):
         F_.DEFER_REDUCTIONS = defer
+        F_.DEFER_FP32 = defer   # (the fp32 path defers only on request: LIC_DEFER_FP32=1)
         for p in m.parameters():
             p.grad = None
         for _ in range(passes):
@@ -214,16 +216,21 @@ def test_deferred_reductions_change_no_bit():
         # one weight, two uses
         w = (torch.randn(128, 128, 3, 3, device=dev) * 0.05).requires_grad_(True)
         b = torch.zeros(128, device=dev, requires_grad=True)
-        xin = torch.randn(2, 128, 16, 16, device=dev).to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        xin = torch.randn(2, 128, 16, 16, device=dev).contiguous(memory_format=torch.channels_last)
+        if precision == "bf16":
+            xin = xin.to(torch.bfloat16)
 
         def twice(defer):
-            F_.DEFER_REDUCTIONS = defer
+            F_.DEFER_REDUCTIONS = F_.DEFER_FP32 = defer
             w.grad = b.grad = None
-            y = FB.conv2d_bf16(FB.conv2d_bf16(xin, w, b, 1, 1), w, b, 1, 1, out_f32=True)
+            if precision == "bf16":
+                y = FB.conv2d_bf16(FB.conv2d_bf16(xin, w, b, 1, 1), w, b, 1, 1, out_f32=True)
+            else:
+                y = F_.conv2d(F_.conv2d(xin, w, b, 1, 1), w, b, 1, 1)
             y.square().mean().backward()
             torch.cuda.synchronize()
             return w.grad.clone(), b.grad.clone()
         (wa, ba), (wb, bb) = twice(True), twice(False)
         assert torch.equal(wa, wb) and torch.equal(ba, bb)
     finally:
-        F_.DEFER_REDUCTIONS = True
+        F_.DEFER_REDUCTIONS, F_.DEFER_FP32 = True, False
