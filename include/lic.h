@@ -339,6 +339,10 @@ int lic_colsum_bf16(const void* in, int64_t ld, int64_t P, int32_t C, float scal
 int lic_leaky_bwd_bf16(const void* y, const void* dy, void* dx, int64_t n, float slope, lic_stream_t stream);
 int lic_gdn_dnorm_bf16(const void* g, const void* x, const void* norm, void* t, int64_t n, int32_t inverse,
                        lic_stream_t stream);
+/* lic_quantize (Models.py:55-64) that also writes the bf16 copies the bf16-storage consumers read: v_bf16 = bf16(v) (the
+ * hyper-encoder's input), out_bf16 = bf16(out) (decoder, context model, hyper-decoder); either may be NULL; n % 4 == 0 */
+int lic_quantize_bf16(const float* v, const float* u, float* out, void* v_bf16, void* out_bf16, int64_t n,
+                      int32_t training, lic_stream_t stream);
 
 /* ---- misc ---------------------------------------------------------------------------------- */
 /* ------------------------------------------------------------------------------------------

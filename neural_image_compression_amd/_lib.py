@@ -129,6 +129,7 @@ SIGNATURES = {
     "lic_col2im_bf16": (C.c_int, [_vp, _vp, _vp] + [_i32] * 11 + [_vp]),
     "lic_colsum_bf16_workspace_bytes": (_sz, [_i64, _i32]),
     "lic_colsum_bf16": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _vp, _vp, _sz, _vp]),
+    "lic_quantize_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
     "lic_wgrad_bf16_partial": (C.c_int, [C.POINTER(WgradDesc), _vp, _sz, C.POINTER(ReduceJob), _vp]),
     "lic_wgrad_partial": (C.c_int, [C.POINTER(WgradDesc), _vp, _sz, C.POINTER(ReduceJob), _vp]),
     "lic_colsum_partial": (C.c_int, [_vp, _i64, _i64, _i32, _f32, _vp, _vp, _sz, C.POINTER(ReduceJob), _vp]),

@@ -166,6 +166,42 @@ LIC_EXPORT int lic_colsum_bf16(const void* in, int64_t ld, int64_t P, int32_t C,
                      scale, out, (float*)nullptr);
   return lic_check_launch();
 }
+// The quantisation surrogate (Models.py:55-64) with the bf16 copies its consumers need written by the same launch:
+// out = v + (u - 0.5) (training) or rint(v); v16 = bf16(v) for the hyper-encoder, out16 = bf16(out) for the decoder, the
+// context model and the hyper-decoder (either may be NULL) -- each was a cast launch of its own.  n % 4 == 0.
+__global__ __launch_bounds__(256) void quantize_bf16_kernel(const float* v, const float* u, float* out, bf16_t* v16,
+                                                            bf16_t* out16, long n4, int training) {
+  typedef float q_f32x4 __attribute__((ext_vector_type(4)));
+  typedef bf16_t q_bf16x4 __attribute__((ext_vector_type(4)));
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+    const q_f32x4 a = reinterpret_cast<const q_f32x4*>(v)[i];
+    q_f32x4 o;
+    if (training) {
+      const q_f32x4 r = reinterpret_cast<const q_f32x4*>(u)[i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = a[e] + (r[e] - 0.5f);
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = rintf(a[e]);
+    }
+    reinterpret_cast<q_f32x4*>(out)[i] = o;
+    if (v16) reinterpret_cast<q_bf16x4*>(v16)[i] = __builtin_convertvector(a, q_bf16x4);
+    if (out16) reinterpret_cast<q_bf16x4*>(out16)[i] = __builtin_convertvector(o, q_bf16x4);
+  }
+}
+LIC_EXPORT int lic_quantize_bf16(const float* v, const float* u, float* out, void* v_bf16, void* out_bf16, int64_t n,
+                                 int32_t training, lic_stream_t stream) {
+  if (!v || !out || n < 0 || (training && !u)) return LIC_ERR_INVALID;
+  if (n % 4 || (reinterpret_cast<uintptr_t>(v) & 15) || (reinterpret_cast<uintptr_t>(out) & 15) ||
+      (u && (reinterpret_cast<uintptr_t>(u) & 15)) || (reinterpret_cast<uintptr_t>(v_bf16) & 7) ||
+      (reinterpret_cast<uintptr_t>(out_bf16) & 7))
+    return LIC_ERR_UNSUPPORTED;
+  if (n == 0) return LIC_OK;
+  hipLaunchKernelGGL(quantize_bf16_kernel, dim3(ew_grid(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, v, u, out,
+                     (bf16_t*)v_bf16, (bf16_t*)out_bf16, (long)(n / 4), training);
+  return lic_check_launch();
+}
+
 // stage 1 only; `job` (two of them for the pair variant) receives stage 2 for a later lic_reduce_batch
 LIC_EXPORT int lic_colsum_bf16_partial(const void* in, int64_t ld, int64_t P, int32_t C, float scale, float* out,
                                        void* workspace, size_t workspace_bytes, lic_reduce_job* job, lic_stream_t stream) {

@@ -1000,26 +1000,53 @@ def gdn(x, beta, gamma, inverse, beta_bound, gamma_bound, pedestal=PEDESTAL, res
 # ------------------------------------------------------------------------------------------
 # quantisation surrogate (Models.py:55-64)
 # ------------------------------------------------------------------------------------------
+_QUANT_CASTS = [None, None]   # (bf16 of the input, bf16 of the result) of the _QuantizeFn.forward that just ran
+
+
 class _QuantizeFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, v, u, training):
+    def forward(ctx, v, u, training, cast_in=False, cast_out=False):
         _require_cuda(v, u)
         vh = _nhwc(v)
         uh = None if u is None else _nhwc(u)
         out = torch.empty_like(vh)
-        L.check(L.load().lic_quantize(_ptr(vh), _ptr(uh), _ptr(out), vh.numel(), int(training), _stream()),
-                "lic_quantize")
+        _QUANT_CASTS[0] = _QUANT_CASTS[1] = None
+        if (cast_in or cast_out) and vh.numel() % 4 == 0:
+            # the bf16 copies the bf16-storage consumers of v / of the result would each make with a cast launch
+            v16 = torch.empty_like(vh, dtype=torch.bfloat16) if cast_in else None
+            o16 = torch.empty_like(vh, dtype=torch.bfloat16) if cast_out else None
+            L.check(L.load().lic_quantize_bf16(_ptr(vh), _ptr(uh), _ptr(out), _ptr(v16), _ptr(o16), vh.numel(),
+                                               int(training), _stream()), "lic_quantize_bf16")
+            _QUANT_CASTS[0], _QUANT_CASTS[1] = v16, o16
+        else:
+            L.check(L.load().lic_quantize(_ptr(vh), _ptr(uh), _ptr(out), vh.numel(), int(training), _stream()),
+                    "lic_quantize")
         ctx.training = training
         return _nchw_view(out)
 
     @staticmethod
     def backward(ctx, g):
         # additive noise: identity; round(): zero gradient (as torch.round)
-        return (g if ctx.training else torch.zeros_like(g)), None, None
+        return (g if ctx.training else torch.zeros_like(g)), None, None, None, None
 
 
-def quantize(v, u=None, training=True):
-    return _QuantizeFn.apply(v, u, training)
+def attach_bf16(t: torch.Tensor, t16_nhwc: Optional[torch.Tensor]):
+    """remember the bf16 NHWC copy of `t` that some launch already wrote, for functional_bf16's input casts (valid while
+    `t` is not modified in place: the version counter is checked on use)"""
+    if t16_nhwc is not None:
+        t._lic_bf16 = (t._version, t16_nhwc)
+
+
+def quantize(v, u=None, training=True, cast_in=False, cast_out=False):
+    """`cast_in` / `cast_out`: the same launch also writes bf16(v) / bf16(result) and attaches them to `v` / the result
+    (attach_bf16): the bf16-storage layers that consume them skip their cast launches"""
+    if not (cast_in or cast_out):
+        return _QuantizeFn.apply(v, u, training)
+    res = _QuantizeFn.apply(v, u, training, cast_in, cast_out)
+    attach_bf16(v, _QUANT_CASTS[0])
+    attach_bf16(res, _QUANT_CASTS[1])
+    _QUANT_CASTS[0] = _QUANT_CASTS[1] = None
+    return res
 
 
 # ------------------------------------------------------------------------------------------

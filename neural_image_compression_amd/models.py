@@ -66,6 +66,11 @@ class _HyperpriorContextModel(nn.Module):
         if self.use_step_prep and x.is_cuda:
             self.step_prep().run()   # one launch: every packed weight / GDN re-parametrisation of this step
         y = self.encoder(x)
+        # bf16-storage consumers of y (hyper-encoder), y_in (decoder, context model) and z_in (hyper-decoder): their bf16
+        # copies come out of the quantisation launches instead of one cast launch per consumer
+        fuse = x.is_cuda and os.environ.get("LIC_QUANT_CASTS", "1") != "0"
+        lat16 = fuse and self.hyper_encoder.precision == "bf16"
+        dec16 = fuse and self.decoder.precision == "bf16"
         if training:
             if noise is None:
                 # the reference draws rand_like(z) then rand_like(y) (Models.py:57-58); z's shape is known
@@ -80,13 +85,13 @@ class _HyperpriorContextModel(nn.Module):
                 uy = u[nz:].view(Bn, hy, wy, Mc).permute(0, 3, 1, 2)
             else:
                 uz, uy = noise
-            y_in = F_.quantize(y, uy, True)
+            y_in = F_.quantize(y, uy, True, cast_in=lat16, cast_out=dec16 or lat16)
         else:
-            y_in = F_.quantize(y, None, False)
+            y_in = F_.quantize(y, None, False, cast_in=lat16, cast_out=dec16 or lat16)
         if _fork is not None:
             _fork(y_in)
         z = self.hyper_encoder(y)
-        z_in = F_.quantize(z, uz, True) if training else F_.quantize(z, None, False)
+        z_in = F_.quantize(z, uz, True, cast_out=lat16) if training else F_.quantize(z, None, False, cast_out=lat16)
         both = (self.context_model.precision, self.hyper_decoder.precision)
         if x.is_cuda and (both == ("fp32", "fp32") or (both == ("bf16", "bf16") and not self.hyper_decoder.out_f32)):
             # Models.py:73 `torch.cat([phi, psi], dim=1)` without the copy: the context conv and the hyper
