@@ -1,6 +1,7 @@
 // HBM-bound helpers of the bf16-storage path (BASELINE config 3): patch<->column conversion
 // with bf16 columns, column sums and the GDN dL/dnorm map on bf16 tensors.  fp32 arithmetic inside.
 #include "lic_common.h"
+#include <stdlib.h>
 #include "lic_patch.h"
 
 typedef __bf16 bf16_t;
@@ -29,12 +30,80 @@ __global__ __launch_bounds__(256) void im2col_bf16_kernel(const float* x, bf16_t
     col[i] = (bf16_t)v;
   }
 }
+// The RGB geometry (C = 3, 5x5, stride 2, padding 2, Kpad = 80), one lane per output pixel: the 15 values a pixel takes
+// from image row 2 oy - 2 + r are 15 CONSECUTIVE floats of the NHWC image (the stem kernel's observation), so a column
+// row is five runs of 15 -- four 16-byte loads each, no lookup table, no per-element index arithmetic -- and leaves the
+// lane as ten 16-byte stores; neighbouring lanes write neighbouring 160-byte rows.  (The generic kernel gathers every
+// element through a table: 66 us for the 84 MB column matrix of a 256^2 x 32 batch, twice per bf16 step.)
+__global__ __launch_bounds__(256) void im2col_rgb5_bf16_kernel(const float* x, bf16_t* col, long npix, int H, int W, int Ho,
+                                                               int Wo) {
+  typedef float i2_f32x4u __attribute__((ext_vector_type(4), aligned(4)));
+  typedef unsigned i2_u32x4 __attribute__((ext_vector_type(4)));
+  const int rowf = 3 * W;
+  for (long pix = (long)blockIdx.x * 256 + threadIdx.x; pix < npix; pix += (long)gridDim.x * 256) {
+    const long t = pix / Wo;
+    const int ow = (int)(pix - t * Wo);
+    const long b = t / Ho;
+    const int oh = (int)(t - b * Ho);
+    const float* img = x + b * (long)H * rowf;
+    const int cf0 = (2 * ow - 2) * 3;                   // first of the 15 floats within an image row
+    const bool colfast = cf0 >= 0 && cf0 + 16 <= rowf;  // (16: the fourth 16-byte load reads one float too many)
+    float v[80];
+#pragma unroll
+    for (int r = 0; r < 5; ++r) {
+      const int ih = 2 * oh - 2 + r;
+      const bool rowok = ih >= 0 && ih < H;
+      const float* src = img + (long)(rowok ? ih : 0) * rowf;
+      if (colfast) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const i2_f32x4u w4 = *reinterpret_cast<const i2_f32x4u*>(src + cf0 + 4 * q);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (4 * q + e < 15) v[15 * r + 4 * q + e] = rowok ? w4[e] : 0.0f;
+        }
+      } else {  // image border: element-wise, zero outside
+#pragma unroll
+        for (int j = 0; j < 15; ++j) {
+          const int c = cf0 + j;
+          const bool ok = rowok && c >= 0 && c < rowf;
+          const float tv = src[ok ? c : 0];
+          v[15 * r + j] = ok ? tv : 0.0f;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 75; j < 80; ++j) v[j] = 0.0f;
+    i2_u32x4* dst = reinterpret_cast<i2_u32x4*>(col + pix * 80);
+#pragma unroll
+    for (int q = 0; q < 10; ++q) {
+      i2_u32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        typedef float i2_f32x2 __attribute__((ext_vector_type(2)));
+        typedef bf16_t i2_bf16x2 __attribute__((ext_vector_type(2)));
+        const i2_f32x2 pr = {v[8 * q + 2 * e], v[8 * q + 2 * e + 1]};
+        o[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(pr, i2_bf16x2));
+      }
+      dst[q] = o;
+    }
+  }
+}
+
 LIC_EXPORT int lic_im2col_bf16(const float* x, void* col, int32_t B, int32_t H, int32_t W, int32_t C, int32_t Ho,
                                int32_t Wo, int32_t kh, int32_t kw, int32_t stride, int32_t pad, int32_t Kpad,
                                lic_stream_t stream) {
   if (!x || !col || B <= 0 || H <= 0 || W <= 0 || C <= 0 || Ho <= 0 || Wo <= 0 || Kpad < kh * kw * C)
     return LIC_ERR_INVALID;
   const long total = (long)B * Ho * Wo * Kpad;
+  if (C == 3 && kh == 5 && kw == 5 && stride == 2 && pad == 2 && Kpad == 80 && Ho == (H + 1) / 2 && Wo == (W + 1) / 2 &&
+      (reinterpret_cast<uintptr_t>(col) & 15) == 0 && (reinterpret_cast<uintptr_t>(x) & 3) == 0 &&
+      getenv("LIC_IM2COL_GENERIC") == nullptr) {
+    const long npix = (long)B * Ho * Wo;
+    hipLaunchKernelGGL(im2col_rgb5_bf16_kernel, dim3(ew_grid(npix, 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       (bf16_t*)col, npix, H, W, Ho, Wo);
+    return lic_check_launch();
+  }
   if (Kpad <= LIC_PATCH_MAXK && Kpad % 8 == 0 && total / 8 < 0x7FFFFFFFL &&
       (reinterpret_cast<uintptr_t>(col) & 15) == 0 && kh < 256 && kw < 256 && C < 256 && (long)H * W * C < 0x7FFFFFFFL)
     hipLaunchKernelGGL((im2col_vec_kernel<bf16_t, 8>), dim3(ew_grid(total / 8, 256)), dim3(256), 0,

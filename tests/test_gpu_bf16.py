@@ -412,6 +412,33 @@ def test_image_layers_bf16(env):
     scale_close(host(tbt.grad), dbf, 1e-4, "head db")
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 21, 19), (1, 64, 64), (3, 6, 5), (1, 2, 2)])
+def test_im2col_rgb5_matches_the_generic_gather(env, monkeypatch, B, H, W):
+    """the one-lane-per-pixel im2col of the RGB 5x5 stride-2 geometry (lic_im2col_bf16's fast path) against the generic
+    table-driven gather it replaces: every border case, bit for bit"""
+    nic, FB, O, d = env
+    from neural_image_compression_amd import _lib as L
+    from neural_image_compression_amd.functional import _ptr, _stream
+    lib = L.load()
+    x = torch.randn(B, H, W, 3, device=d)
+    Ho, Wo = (H + 1) // 2, (W + 1) // 2
+    cols = []
+    for generic in (False, True):
+        if generic:
+            monkeypatch.setenv("LIC_IM2COL_GENERIC", "1")
+        col = torch.full((B * Ho * Wo, 80), float("nan"), device=d, dtype=BF)
+        L.check(lib.lic_im2col_bf16(_ptr(x), _ptr(col), B, H, W, 3, Ho, Wo, 5, 5, 2, 2, 80, _stream()), "lic_im2col_bf16")
+        torch.cuda.synchronize()
+        cols.append(col)
+    assert torch.equal(cols[0].view(torch.int16), cols[1].view(torch.int16))
+    # against the definition, for one sample of entries
+    xp = torch.nn.functional.pad(x.permute(0, 3, 1, 2), (2, 2, 2, 2))
+    ref = xp.unfold(2, 5, 2).unfold(3, 5, 2)            # [B, 3, Ho, Wo, 5, 5]
+    ref = ref.permute(0, 2, 3, 4, 5, 1).reshape(B * Ho * Wo, 75).to(BF)
+    assert torch.equal(cols[0][:, :75].view(torch.int16), ref.contiguous().view(torch.int16))
+    assert float(cols[0][:, 75:].abs().max()) == 0.0
+
+
 # the RGB head without column matrices (lic_head_convt_bf16: features -> image in one launch; lic_stem_conv_bf16: its data
 # gradient as a direct convolution of the image gradient): partial tiles in both directions, every supported width,
 # against the oracle on bf16-exact operands (fp32 accumulation of exact products: tight) and against the column-matrix
