@@ -393,6 +393,14 @@ LIC_EXPORT int lic_plan_tune(lic_plan* p, lic_stream_t main_, const lic_stream_t
   if (rc != LIC_OK) return rc;
   double total = 0.0;
   for (const PlanOp& op : p->ops) total += op.us;
+  if (const char* dbg = getenv("LIC_PLAN_DEBUG"))
+    if (dbg[0] == '2')   // the step as a list of stand-alone operation times (capture order)
+      for (size_t k = 0; k < n; ++k) {
+        const PlanOp& op = p->ops[k];
+        const char* nm = op.type == hipGraphNodeTypeKernel ? hipKernelNameRefByPtr(op.kp.func, main) : "(memset / memcpy / empty)";
+        fprintf(stderr, "[lic_plan] op %3zu %8.1f us  grid %6u  %s\n", k, op.us,
+                op.type == hipGraphNodeTypeKernel ? op.kp.gridDim.x * op.kp.gridDim.y * op.kp.gridDim.z : 0u, nm ? nm : "?");
+      }
   // ---- 2. list scheduling.  Priority = longest path to the end (own time included).  Repeatedly the (ready
   //         operation, stream) pair that can START earliest is placed (ties: the more critical operation; a
   //         cross-stream dependency costs SYNC_US, so a chain stays on its stream unless the other one is clearly
