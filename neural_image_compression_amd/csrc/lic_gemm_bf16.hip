@@ -1332,7 +1332,12 @@ static int wgh_plan(const lic_wgrad_desc* d, WgHPlan* pl) {
   const long base = (long)pl->MTt * pl->NTt * pl->ntaps;
   const long max_sk = (pl->nchunks + 15) / 16;  // at least 16 chunks (512 pixels) per split
   // resident workgroups per CU: 2 for the 5-6 sub-tile variants (registers / 72 KiB LDS), else 3
-  const long sk = lic_pick_splits(base, 256L * (pl->TM + pl->TN >= 5 ? 2 : 3), max_sk);
+  long per_cu = pl->TM + pl->TN >= 5 ? 2 : 3;
+  if (const char* e = getenv("LIC_WGRAD_BF16_ROUND")) {   // tuning aid: workgroups per CU one round of splits should fill
+    const long v = atol(e);
+    if (v >= 1 && v <= 3) per_cu = v < per_cu ? v : per_cu;
+  }
+  const long sk = lic_pick_splits(base, 256L * per_cu, max_sk);
   pl->cps = (int)((pl->nchunks + sk - 1) / sk);
   pl->splitk = (pl->nchunks + pl->cps - 1) / pl->cps;
   return LIC_OK;
