@@ -327,8 +327,13 @@ int lic_col2im_bf16(const void* col, const float* bias, float* out, int32_t B, i
  * it), dx = g * norm^-1/2 + 2 x (t . gamma_eff) (inverse: norm^+1/2).  g, x, norm, dx, t: dense bf16 [P][C];
  * gamma_packed = lic_pack_weight_bf16_kperm(gamma_eff, taps 1, K = C, N = C, s_k = C, s_n = 1). */
 int lic_gdn_bwd_bf16_supported(int32_t C);
+/* colsum_*_partial (optional, both or neither): [lic_gdn_bwd_bf16_partial_rows(P)][C] fp32 per-workgroup column sums of t
+ * and of dx -- d beta and the d bias of the convolution in front need one small reduction over these rows instead of a
+ * pass over the two activations */
+int64_t lic_gdn_bwd_bf16_partial_rows(int64_t P);
 int lic_gdn_bwd_bf16(const void* g, const void* x, const void* norm, const void* gamma_packed, void* dx, void* t,
-                     int64_t P, int32_t C, int32_t inverse, lic_stream_t stream);
+                     float* colsum_t_partial, float* colsum_dx_partial, int64_t P, int32_t C, int32_t inverse,
+                     lic_stream_t stream);
 /* column sums of two bf16 [P][ld] matrices of one shape in one launch pair (workspace: twice the single size) */
 int lic_colsum2_bf16(const void* in_a, const void* in_b, int64_t ld, int64_t P, int32_t C, float scale, float* out_a,
                      float* out_b, void* workspace, size_t workspace_bytes, lic_stream_t stream);

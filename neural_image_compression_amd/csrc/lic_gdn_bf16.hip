@@ -30,17 +30,44 @@ struct GdnBwdHParams {
   const gb_bf16* gamma;  // gamma_eff packed by lic_pack_weight_bf16_kperm(taps 1, K = C (norm index), N = C, s_k = C, s_n = 1)
   gb_bf16* dx;
   gb_bf16* t;
+  float* cs_t;   // optional: [gridDim.x][C] per-workgroup column sums of t (-> d beta) ...
+  float* cs_dx;  // ... and of dx (-> the d bias of the convolution in front); both or neither
   long P;
   int inverse;
 };
 
-template <int NT4>  // C / 32
+// CS: also the column sums of t and dx.  d beta and the convolution's d bias are the column sums of two tensors this kernel
+// has just produced; a separate launch re-read both (2 x 134 MB at 128^2 x 32 x 128 channels, 58-64 us) for 256 numbers.
+// Here a wave parks its 32 x C tile of t (then of dx) in LDS as written -- rows 16 bytes apart from a multiple of 256 so
+// that the 16-byte row writes spread over the banks -- and every lane sums one channel PAIR down the 32 rows; the sums
+// stay in two registers per tensor across the workgroup's tiles and leave as one [C] row per workgroup for the pass's
+// batched reduction (lic_reduce_batch, COLUMNS).
+template <int NT4, bool CS = false>  // C / 32
 __global__ __launch_bounds__(256, NT4 <= 2 ? 2 : 1) void gdn_bwd_bf16_kernel(const GdnBwdHParams p) {
   constexpr int C = 32 * NT4, NG = C / 16;
+  constexpr int CSLD = C / 2 + 4;   // dwords per parked row
   __shared__ __attribute__((aligned(16))) gb_bf16 gam[C * C];  // [chunk = C/32][tile = C/32][2][64 lanes][8]
+  __shared__ __attribute__((aligned(16))) unsigned park[CS ? 4 * 32 * CSLD : 4];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 31, lh = lane >> 5;
+  float cst[2] = {0.f, 0.f}, csd[2] = {0.f, 0.f};   // column sums of channels 2 lane, 2 lane + 1 (lanes < C / 2)
+  unsigned* mypark = park + (CS ? wave * 32 * CSLD : 0);
+  auto colsum_tile = [&](float (&accum)[2]) {   // after the wave's lanes wrote their rows
+    __builtin_amdgcn_wave_barrier();
+    if (lane < C / 2) {
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 32; ++r) {
+        const unsigned u = mypark[r * CSLD + lane];
+        a0 += __builtin_bit_cast(float, u << 16);
+        a1 += __builtin_bit_cast(float, u & 0xffff0000u);
+      }
+      accum[0] += a0;
+      accum[1] += a1;
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
   // gamma panel: C*C*2 bytes, 16 bytes per thread per pass
 #pragma unroll
   for (int i = 0; i < C * C / 8 / 256; ++i)
@@ -81,11 +108,13 @@ __global__ __launch_bounds__(256, NT4 <= 2 ? 2 : 1) void gdn_bwd_bf16_kernel(con
         tq[d] = pack2(t0, t1);
       }
       if (rok) *reinterpret_cast<gb_u32x4*>(p.t + off + 16 * s) = tq;
+      if (CS) *reinterpret_cast<gb_u32x4*>(mypark + li * CSLD + 8 * s + 4 * lh) = rok ? tq : gb_u32x4{0u, 0u, 0u, 0u};
       // lanes li / li + 32 hold channels 0..7 / 8..15 of the group; the kperm operand wants {0..3, 8..11} / {4..7, 12..15}
       const gb_u32x2 a = __builtin_amdgcn_permlane32_swap(tq[0], tq[2], false, false);
       const gb_u32x2 b = __builtin_amdgcn_permlane32_swap(tq[1], tq[3], false, false);
       tb[s] = gb_u32x4{a[0], b[0], a[1], b[1]};
     }
+    if (CS) colsum_tile(cst);
     // ---- pool^T[co][pixel] = sum_ci gamma_eff[ci][co] t[pixel][ci]   (A = gamma from LDS, B = t from registers)
     f32x16 acc[NT4];
 #pragma unroll
@@ -131,6 +160,25 @@ __global__ __launch_bounds__(256, NT4 <= 2 ? 2 : 1) void gdn_bwd_bf16_kernel(con
         dq[d] = pack2(d0, d1);
       }
       if (rok) *reinterpret_cast<gb_u32x4*>(p.dx + off + 16 * s) = dq;
+      if (CS) *reinterpret_cast<gb_u32x4*>(mypark + li * CSLD + 8 * s + 4 * lh) = rok ? dq : gb_u32x4{0u, 0u, 0u, 0u};
+    }
+    if (CS) colsum_tile(csd);
+  }
+  if (CS) {   // the four waves' sums -> one row per workgroup (fixed order)
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(park);   // [2][4][C]
+    if (lane < C / 2) {
+      red[(0 * 4 + wave) * C + 2 * lane] = cst[0];
+      red[(0 * 4 + wave) * C + 2 * lane + 1] = cst[1];
+      red[(1 * 4 + wave) * C + 2 * lane] = csd[0];
+      red[(1 * 4 + wave) * C + 2 * lane + 1] = csd[1];
+    }
+    __syncthreads();
+    if (tid < 2 * C) {
+      const int which = tid / C, c = tid - which * C;
+      const float* q = red + which * 4 * C + c;
+      const float v = (q[0] + q[C]) + (q[2 * C] + q[3 * C]);
+      (which ? p.cs_dx : p.cs_t)[(long)blockIdx.x * C + c] = v;
     }
   }
 }
@@ -141,17 +189,31 @@ LIC_EXPORT int lic_gdn_bwd_bf16_supported(int32_t C) { return C == 64 || C == 12
 
 // g, x, norm, dx, t: dense bf16 [P][C]; gamma_packed: lic_pack_weight_bf16_kperm(gamma_eff, taps 1, K = C, N = C,
 // s_k = C, s_n = 1)
+static unsigned gdn_bwd_bf16_grid(int64_t P) {
+  const long ntile = (P + 127) / 128;
+  return (unsigned)(ntile < 2048 ? ntile : 2048);
+}
+// rows of the optional per-workgroup column-sum outputs of lic_gdn_bwd_bf16
+LIC_EXPORT int64_t lic_gdn_bwd_bf16_partial_rows(int64_t P) { return P <= 0 ? 0 : (int64_t)gdn_bwd_bf16_grid(P); }
+
 LIC_EXPORT int lic_gdn_bwd_bf16(const void* g, const void* x, const void* norm, const void* gamma_packed, void* dx,
-                                void* t, int64_t P, int32_t C, int32_t inverse, lic_stream_t stream) {
+                                void* t, float* colsum_t_partial, float* colsum_dx_partial, int64_t P, int32_t C,
+                                int32_t inverse, lic_stream_t stream) {
   if (!g || !x || !norm || !gamma_packed || !dx || !t || P <= 0) return LIC_ERR_INVALID;
+  if ((colsum_t_partial == nullptr) != (colsum_dx_partial == nullptr)) return LIC_ERR_INVALID;
   if (!lic_gdn_bwd_bf16_supported(C)) return LIC_ERR_UNSUPPORTED;
   for (const void* q : {g, x, norm, gamma_packed, (const void*)dx, (const void*)t})
     if (reinterpret_cast<uintptr_t>(q) & 15) return LIC_ERR_INVALID;
   GdnBwdHParams p{(const gb_bf16*)g, (const gb_bf16*)x, (const gb_bf16*)norm, (const gb_bf16*)gamma_packed,
-                  (gb_bf16*)dx, (gb_bf16*)t, (long)P, inverse ? 1 : 0};
-  const long ntile = (P + 127) / 128;
-  const unsigned grid = (unsigned)(ntile < 2048 ? ntile : 2048);
-  if (C == 64) hipLaunchKernelGGL((gdn_bwd_bf16_kernel<2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL((gdn_bwd_bf16_kernel<4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+                  (gb_bf16*)dx, (gb_bf16*)t, colsum_t_partial, colsum_dx_partial, (long)P, inverse ? 1 : 0};
+  const unsigned grid = gdn_bwd_bf16_grid(P);
+  hipStream_t s = (hipStream_t)stream;
+  if (colsum_t_partial) {
+    if (C == 64) hipLaunchKernelGGL((gdn_bwd_bf16_kernel<2, true>), dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gdn_bwd_bf16_kernel<4, true>), dim3(grid), dim3(256), 0, s, p);
+  } else {
+    if (C == 64) hipLaunchKernelGGL((gdn_bwd_bf16_kernel<2>), dim3(grid), dim3(256), 0, s, p);
+    else hipLaunchKernelGGL((gdn_bwd_bf16_kernel<4>), dim3(grid), dim3(256), 0, s, p);
+  }
   return lic_check_launch();
 }

@@ -180,6 +180,24 @@ def _colsum_bf16(t2d, P, Cc, defer=False, reparam=None):
     return out
 
 
+def _rows_sum(part, defer=False, reparam=None):
+    """column sums of a small fp32 [rows][C] matrix of partial sums (the per-workgroup rows lic_gdn_bwd_bf16 leaves):
+    pending (`defer`: one COLUMNS job of the pass's batched reduction, optionally with the re-parametrisation's
+    backward) or right away (a one-job lic_reduce_batch)"""
+    from . import functional as F_
+    rows, Cc = part.shape
+    out = torch.empty((Cc,), device=part.device, dtype=torch.float32)
+    job = L.ReduceJob()
+    job.src, job.dst, job.kind, job.splitk, job.Cn, job.scale = part.data_ptr(), out.data_ptr(), L.REDUCE_COLUMNS, rows, Cc, 1.0
+    if not defer:   # the same kernel, now (so that deferring changes no bit)
+        L.check(L.load().lic_reduce_batch(C.byref(job), 1, _stream()), "lic_reduce_batch")
+        return out
+    if reparam is not None:
+        _reparam_epilogue(job, *reparam)
+    F_.defer(job, part, reparam[0] if reparam is not None else None)
+    return out
+
+
 def _colsum2_bf16(a2d, b2d, P, Cc, defer=False, reparam_a=None):
     """column sums of two bf16 [P][Cc] matrices in one launch pair (`defer` / `reparam_a`: as _colsum_bf16, the
     re-parametrisation applies to the first matrix's sums)"""
@@ -524,6 +542,7 @@ def _gdn_backward_bf16(xh, norm, beta, gamma, g, inverse, beta_bound, gamma_boun
     P = B * H * W
     t = torch.empty_like(xh)
     dxh = dbeta = dgamma = None
+    part_t = part_dx = None
     if need_dx and lib.lic_gdn_bwd_bf16_supported(Cc) and os.environ.get("LIC_BF16_GDN_BWD", "1") != "0":
         # one sweep: g, x, norm read once, t and dx written (lic_gdn_bf16.hip); the two-launch route below moves
         # 1.8x the bytes
@@ -534,9 +553,16 @@ def _gdn_backward_bf16(xh, norm, beta, gamma, g, inverse, beta_bound, gamma_boun
         from . import functional as F_
         if F_.KERNEL_TRACE is not None:
             F_.KERNEL_TRACE.add(f"gdn_bwd_bf16_kernel<{Cc // 32}>")
+        if need_dbeta and os.environ.get("LIC_BF16_GDN_BWD_CS", "1") != "0":
+            # the kernel also leaves per-workgroup column sums of t and dx: d beta (and the convolution's d bias) need
+            # one small reduction over those rows instead of a pass over the two activations
+            rows = lib.lic_gdn_bwd_bf16_partial_rows(P)
+            part_t = torch.empty((rows, Cc), device=xh.device, dtype=torch.float32)
+            part_dx = torch.empty((rows, Cc), device=xh.device, dtype=torch.float32)
         F_._timed(f"gdn_bwd_bf16_kernel<{Cc // 32}>", 2 * P * Cc * Cc, 10 * P * Cc,
-                  lambda: L.check(lib.lic_gdn_bwd_bf16(_ptr(g), _ptr(xh), _ptr(norm), _ptr(gp), _ptr(dxh), _ptr(t), P, Cc,
-                                                       int(inverse), _stream()), "lic_gdn_bwd_bf16"))
+                  lambda: L.check(lib.lic_gdn_bwd_bf16(_ptr(g), _ptr(xh), _ptr(norm), _ptr(gp), _ptr(dxh), _ptr(t),
+                                                       _ptr(part_t), _ptr(part_dx), P, Cc, int(inverse), _stream()),
+                                  "lic_gdn_bwd_bf16"))
     else:
         L.check(lib.lic_gdn_dnorm_bf16(_ptr(g), _ptr(xh), _ptr(norm), _ptr(t), xh.numel(), int(inverse), _stream()),
                 "lic_gdn_dnorm_bf16")
@@ -554,7 +580,11 @@ def _gdn_backward_bf16(xh, norm, beta, gamma, g, inverse, beta_bound, gamma_boun
         # pending reductions that end in the re-parametrisation's backward: d-beta, d-gamma (and the convolution's bias
         # gradient) come out of the backward pass's one batched launch, no lic_gdn_reparam_bwd2 launch here
         dbeta = dgamma = None
-        if bias_from_dx and need_dbeta and dxh is not None:
+        if need_dbeta and part_t is not None:
+            dbeta = _rows_sum(part_t, defer=True, reparam=(beta_c, beta_bound))
+            if bias_from_dx:
+                db_conv = _rows_sum(part_dx, defer=True)
+        elif bias_from_dx and need_dbeta and dxh is not None:
             dbeta, db_conv = _colsum2_bf16(t, dxh, P, Cc, defer=True, reparam_a=(beta_c, beta_bound))
         elif need_dbeta:
             dbeta = _colsum_bf16(t, P, Cc, defer=True, reparam=(beta_c, beta_bound))
@@ -570,7 +600,11 @@ def _gdn_backward_bf16(xh, norm, beta, gamma, g, inverse, beta_bound, gamma_boun
         if bias_from_dx:
             return dxh, dbeta, dgamma, db_conv
         return dxh, dbeta, dgamma
-    if bias_from_dx and need_dbeta and dxh is not None:
+    if need_dbeta and part_t is not None:
+        dbe = _rows_sum(part_t)
+        if bias_from_dx:
+            db_conv = _rows_sum(part_dx)
+    elif bias_from_dx and need_dbeta and dxh is not None:
         dbe, db_conv = _colsum2_bf16(t, dxh, P, Cc)
     elif need_dbeta:
         dbe = _colsum_bf16(t, P, Cc)

@@ -523,7 +523,7 @@ def test_gdn_bwd_one_sweep_bf16(env, C, P, inverse):
     gamma_e = torch.from_numpy(rb(np.abs(r.randn(C, C)).astype(np.float32) * 0.05)).to(d)   # [norm index][x index]
     gp1 = FB._pack_bf16(gamma_e, 1, C, C, 0, C, 1, kperm=True)
     dx1, t1 = torch.empty_like(x), torch.empty_like(x)
-    L.check(lib.lic_gdn_bwd_bf16(_ptr(g), _ptr(x), _ptr(nrm), _ptr(gp1), _ptr(dx1), _ptr(t1), P, C, int(inverse),
+    L.check(lib.lic_gdn_bwd_bf16(_ptr(g), _ptr(x), _ptr(nrm), _ptr(gp1), _ptr(dx1), _ptr(t1), None, None, P, C, int(inverse),
                                  _stream()), "lic_gdn_bwd_bf16")
     # two-launch route
     t2, dx2 = torch.empty_like(x), torch.empty_like(x)
@@ -544,8 +544,24 @@ def test_gdn_bwd_one_sweep_bf16(env, C, P, inverse):
         nn = nrm.float().cpu().numpy().T.reshape(1, C, P, 1)
         dxo = O.gdn_bwd(xn, nn, gamma_e.cpu().numpy(), gn, inverse)[0]
         scale_close(a.cpu().numpy().T.reshape(1, C, P, 1), dxo, 2e-2, "one-sweep dx against the oracle")
+    # with the per-workgroup column sums: same t and dx bits, and the rows add up to the column sums of the bf16 tensors
+    rows = lib.lic_gdn_bwd_bf16_partial_rows(P)
+    pt = torch.full((rows, C), float("nan"), device=d)
+    pdx = torch.full((rows, C), float("nan"), device=d)
+    dx3, t3 = torch.empty_like(x), torch.empty_like(x)
+    L.check(lib.lic_gdn_bwd_bf16(_ptr(g), _ptr(x), _ptr(nrm), _ptr(gp1), _ptr(dx3), _ptr(t3), _ptr(pt), _ptr(pdx), P, C,
+                                 int(inverse), _stream()), "lic_gdn_bwd_bf16 (column sums)")
+    torch.cuda.synchronize()
+    assert torch.equal(t3, t1) and torch.equal(dx3, dx1)
+    for part, src, what in ((pt, t1, "t"), (pdx, dx1, "dx")):
+        ref = src.double().sum(0)
+        got = part.double().sum(0)
+        tol = 1e-5 * float(src.double().abs().sum(0).max()) + 1e-6     # fp32 partial sums of bf16 values
+        assert float((got - ref).abs().max()) <= tol, (what, float((got - ref).abs().max()), tol)
+    assert lib.lic_gdn_bwd_bf16(_ptr(g), _ptr(x), _ptr(nrm), _ptr(gp1), _ptr(dx3), _ptr(t3), _ptr(pt), None, P, C, 0,
+                                _stream()) == -1   # both or neither
     # unsupported widths and misaligned pointers are refused, not mis-run
-    assert lib.lic_gdn_bwd_bf16(_ptr(g), _ptr(x), _ptr(nrm), _ptr(gp1), _ptr(dx1), _ptr(t1), P, 192, 0, _stream()) \
+    assert lib.lic_gdn_bwd_bf16(_ptr(g), _ptr(x), _ptr(nrm), _ptr(gp1), _ptr(dx1), _ptr(t1), None, None, P, 192, 0, _stream()) \
         == -2   # LIC_ERR_UNSUPPORTED
 
 

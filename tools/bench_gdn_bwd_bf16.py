@@ -42,7 +42,7 @@ for C, side in ((128, 128), (128, 64), (128, 32), (64, 128)):
     dx, t = torch.empty_like(x), torch.empty_like(x)
 
     def one():
-        L.check(lib.lic_gdn_bwd_bf16(_ptr(g), _ptr(x), _ptr(n), _ptr(gp1), _ptr(dx), _ptr(t), P, C, 0, _stream()), "x")
+        L.check(lib.lic_gdn_bwd_bf16(_ptr(g), _ptr(x), _ptr(n), _ptr(gp1), _ptr(dx), _ptr(t), None, None, P, C, 0, _stream()), "x")
 
     def two():
         L.check(lib.lic_gdn_dnorm_bf16(_ptr(g), _ptr(x), _ptr(n), _ptr(t), x.numel(), 0, _stream()), "dnorm")
