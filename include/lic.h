@@ -334,6 +334,13 @@ int64_t lic_gdn_bwd_bf16_partial_rows(int64_t P);
 int lic_gdn_bwd_bf16(const void* g, const void* x, const void* norm, const void* gamma_packed, void* dx, void* t,
                      float* colsum_t_partial, float* colsum_dx_partial, int64_t P, int32_t C, int32_t inverse,
                      lic_stream_t stream);
+/* ... with the pool RECOMPUTED instead of read: norm = beta_eff + x^2 . gamma_eff^T formed as the forward pass forms it
+ * (x^2 and the result rounded to bf16), so the forward pass writes two tensors per GDN layer instead of three and this
+ * launch reads two instead of three.  gammaT_packed = lic_pack_weight_bf16_kperm(gamma_eff, taps 1, K = C, N = C,
+ * s_k = 1, s_n = C) -- the fused conv + GDN kernels' operand. */
+int lic_gdn_bwd_bf16_recompute(const void* g, const void* x, const void* gamma_packed, const void* gammaT_packed,
+                               const float* beta_eff, void* dx, void* t, float* colsum_t_partial,
+                               float* colsum_dx_partial, int64_t P, int32_t C, int32_t inverse, lic_stream_t stream);
 /* column sums of two bf16 [P][ld] matrices of one shape in one launch pair (workspace: twice the single size) */
 int lic_colsum2_bf16(const void* in_a, const void* in_b, int64_t ld, int64_t P, int32_t C, float scale, float* out_a,
                      float* out_b, void* workspace, size_t workspace_bytes, lic_stream_t stream);

@@ -30,6 +30,8 @@ struct GdnBwdHParams {
   const gb_bf16* gamma;  // gamma_eff packed by lic_pack_weight_bf16_kperm(taps 1, K = C (norm index), N = C, s_k = C, s_n = 1)
   gb_bf16* dx;
   gb_bf16* t;
+  const gb_bf16* gammaT;  // RN: gamma_eff^T packed by lic_pack_weight_bf16_kperm(K = C (x index), N = C, s_k = 1, s_n = C)
+  const float* beta;      // RN: beta_eff [C]
   float* cs_t;   // optional: [gridDim.x][C] per-workgroup column sums of t (-> d beta) ...
   float* cs_dx;  // ... and of dx (-> the d bias of the convolution in front); both or neither
   long P;
@@ -42,11 +44,17 @@ struct GdnBwdHParams {
 // that the 16-byte row writes spread over the banks -- and every lane sums one channel PAIR down the 32 rows; the sums
 // stay in two registers per tensor across the workgroup's tiles and leave as one [C] row per workgroup for the pass's
 // batched reduction (lic_reduce_batch, COLUMNS).
-template <int NT4, bool CS = false>  // C / 32
+// RN: the pool norm = beta_eff + x^2 . gamma_eff^T is RECOMPUTED here instead of read (p.norm is not touched): the forward
+// pass then writes two tensors per GDN layer (conv output, y) instead of three and this kernel reads two (g, x) instead of
+// three -- the second C x C contraction costs a memory-bound kernel nothing.  The recomputed norm is rounded to bf16 like
+// the stored one was, so everything downstream is the same arithmetic.
+template <int NT4, bool CS = false, bool RN = false>  // C / 32
 __global__ __launch_bounds__(256, NT4 <= 2 ? 2 : 1) void gdn_bwd_bf16_kernel(const GdnBwdHParams p) {
   constexpr int C = 32 * NT4, NG = C / 16;
   constexpr int CSLD = C / 2 + 4;   // dwords per parked row
   __shared__ __attribute__((aligned(16))) gb_bf16 gam[C * C];  // [chunk = C/32][tile = C/32][2][64 lanes][8]
+  __shared__ __attribute__((aligned(16))) gb_bf16 gamT[RN ? C * C : 8];
+  __shared__ __attribute__((aligned(16))) float s_beta[RN ? C : 4];
   __shared__ __attribute__((aligned(16))) unsigned park[CS ? 4 * 32 * CSLD : 4];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -72,10 +80,18 @@ __global__ __launch_bounds__(256, NT4 <= 2 ? 2 : 1) void gdn_bwd_bf16_kernel(con
 #pragma unroll
   for (int i = 0; i < C * C / 8 / 256; ++i)
     reinterpret_cast<gb_u32x4*>(gam)[i * 256 + tid] = reinterpret_cast<const gb_u32x4*>(p.gamma)[i * 256 + tid];
+  if (RN) {
+#pragma unroll
+    for (int i = 0; i < C * C / 8 / 256; ++i)
+      reinterpret_cast<gb_u32x4*>(gamT)[i * 256 + tid] = reinterpret_cast<const gb_u32x4*>(p.gammaT)[i * 256 + tid];
+    if (tid < C) s_beta[tid] = p.beta[tid];
+  }
   __syncthreads();
 
   const long ntile = (p.P + 127) / 128;
   for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
+    // (without the column sums' wave barriers nothing stops hipcc from hoisting BOTH panels' fragments out of the loop)
+    if (RN && !CS) asm volatile("" ::: "memory");
     const long row = tile * 128 + wave * 32 + li;
     const bool rok = row < p.P;
     const long off = (rok ? row : 0) * C + 8 * lh;
@@ -85,7 +101,7 @@ __global__ __launch_bounds__(256, NT4 <= 2 ? 2 : 1) void gdn_bwd_bf16_kernel(con
     for (int s = 0; s < NG; ++s) {
       gq[s] = *reinterpret_cast<const gb_u32x4*>(p.g + off + 16 * s);
       xq[s] = *reinterpret_cast<const gb_u32x4*>(p.x + off + 16 * s);
-      nq[s] = *reinterpret_cast<const gb_u32x4*>(p.norm + off + 16 * s);
+      if (!RN) nq[s] = *reinterpret_cast<const gb_u32x4*>(p.norm + off + 16 * s);
     }
     auto lo = [](unsigned u) { return __builtin_bit_cast(float, u << 16); };
     auto hi = [](unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); };
@@ -93,6 +109,57 @@ __global__ __launch_bounds__(256, NT4 <= 2 ? 2 : 1) void gdn_bwd_bf16_kernel(con
       const gb_f32x2 v = {a, b};
       return __builtin_bit_cast(unsigned, __builtin_convertvector(v, gb_bf16x2));
     };
+    // a transposed accumulator tile back in the loaded layout: the accumulator of channel tile bo holds, for this lane's
+    // pixel, channels 8 gg + 4 lh + {0..3} (gg = 0..3); group s = 2 bo + (gg >> 1) wants channels 8 lh + {0..7}
+    auto unswap = [&](const f32x16& a16, int s, float (&pl)[8]) {
+      const int g0 = 2 * (s & 1);   // registers 4 g0 .. 4 g0 + 7
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        // (by value first: __builtin_bit_cast on a vector-element lvalue reads element 0 of the vector with this clang)
+        const float q0 = a16[4 * g0 + e], q1 = a16[4 * g0 + 4 + e];
+        const gb_u32x2 sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, q0),
+                                                             __builtin_bit_cast(unsigned, q1), false, false);
+        // low lanes: (own first quad, partner's first quad) = channels e, 4 + e; high lanes: (partner's second quad,
+        // own second quad) = channels 8 + e, 12 + e
+        const unsigned w0 = sw[0], w1 = sw[1];
+        pl[e] = __builtin_bit_cast(float, w0);
+        pl[4 + e] = __builtin_bit_cast(float, w1);
+      }
+    };
+    if (RN) {
+      // ---- norm = beta_eff + x^2 . gamma_eff^T, as the forward pass forms it: x^2 rounded to bf16, fp32 pool, bf16 result
+      f32x16 nacc[NT4];
+#pragma unroll
+      for (int bo = 0; bo < NT4; ++bo)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) nacc[bo][r] = 0.0f;
+#pragma unroll
+      for (int s = 0; s < NG; ++s) {
+        gb_u32x4 sq;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const float x0 = lo(xq[s][d]), x1 = hi(xq[s][d]);
+          sq[d] = pack2(x0 * x0, x1 * x1);
+        }
+        const gb_u32x2 a = __builtin_amdgcn_permlane32_swap(sq[0], sq[2], false, false);
+        const gb_u32x2 b = __builtin_amdgcn_permlane32_swap(sq[1], sq[3], false, false);
+        const gb_bf16x8 b2 = __builtin_bit_cast(gb_bf16x8, gb_u32x4{a[0], b[0], a[1], b[1]});
+#pragma unroll
+        for (int bo = 0; bo < NT4; ++bo) {
+          const gb_bf16x8 a2 = *reinterpret_cast<const gb_bf16x8*>(gamT + (((s >> 1) * NT4 + bo) * 2 + (s & 1)) * 512 + lane * 8);
+          nacc[bo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, nacc[bo], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int s = 0; s < NG; ++s) {
+        float pl[8];
+        unswap(nacc[s >> 1], s, pl);
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(s_beta + 16 * s + 8 * lh);
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(s_beta + 16 * s + 8 * lh + 4);
+        nq[s] = gb_u32x4{pack2(pl[0] + b0[0], pl[1] + b0[1]), pack2(pl[2] + b0[2], pl[3] + b0[3]),
+                         pack2(pl[4] + b1[0], pl[5] + b1[1]), pack2(pl[6] + b1[2], pl[7] + b1[3])};
+      }
+    }
     // ---- t = dL/dnorm, rounded to bf16 (what the d-gamma / d-beta launches read); its kperm B operand
     gb_u32x4 tb[NG];
 #pragma unroll
@@ -130,25 +197,11 @@ __global__ __launch_bounds__(256, NT4 <= 2 ? 2 : 1) void gdn_bwd_bf16_kernel(con
         acc[bo] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2, b2, acc[bo], 0, 0, 0);
       }
     }
-    // ---- dx = g f + 2 x pool, f = norm^-1/2 (IGDN: ^+1/2); the pool goes back to the loaded layout first:
-    // the accumulator of channel tile bo holds, for this lane's pixel, channels 8 gg + 4 lh + {0..3} (gg = 0..3);
-    // group s = 2 bo + (gg >> 1) wants channels 8 lh + {0..7}
+    // ---- dx = g f + 2 x pool, f = norm^-1/2 (IGDN: ^+1/2); the pool goes back to the loaded layout first (unswap)
 #pragma unroll
     for (int s = 0; s < NG; ++s) {
-      const int bo = s >> 1, g0 = 2 * (s & 1);   // registers 4 g0 .. 4 g0 + 7 of acc[bo]
       float pl[8];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        // (by value first: __builtin_bit_cast on a vector-element lvalue reads element 0 of the vector with this clang)
-        const float q0 = acc[bo][4 * g0 + e], q1 = acc[bo][4 * g0 + 4 + e];
-        const gb_u32x2 sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, q0),
-                                                             __builtin_bit_cast(unsigned, q1), false, false);
-        // low lanes: (own first quad, partner's first quad) = channels e, 4 + e; high lanes: (partner's second quad,
-        // own second quad) = channels 8 + e, 12 + e
-        const unsigned w0 = sw[0], w1 = sw[1];
-        pl[e] = __builtin_bit_cast(float, w0);
-        pl[4 + e] = __builtin_bit_cast(float, w1);
-      }
+      unswap(acc[s >> 1], s, pl);
       gb_u32x4 dq;
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
@@ -196,6 +249,21 @@ static unsigned gdn_bwd_bf16_grid(int64_t P) {
 // rows of the optional per-workgroup column-sum outputs of lic_gdn_bwd_bf16
 LIC_EXPORT int64_t lic_gdn_bwd_bf16_partial_rows(int64_t P) { return P <= 0 ? 0 : (int64_t)gdn_bwd_bf16_grid(P); }
 
+static int gdn_bwd_bf16_run(const GdnBwdHParams& p, int C, bool rn, hipStream_t s) {
+  const unsigned grid = gdn_bwd_bf16_grid(p.P);
+#define LIC_GB(nt, cs, rnv) hipLaunchKernelGGL((gdn_bwd_bf16_kernel<nt, cs, rnv>), dim3(grid), dim3(256), 0, s, p)
+  const bool cs = p.cs_t != nullptr;
+  if (C == 64) {
+    if (rn) { if (cs) LIC_GB(2, true, true); else LIC_GB(2, false, true); }
+    else { if (cs) LIC_GB(2, true, false); else LIC_GB(2, false, false); }
+  } else {
+    if (rn) { if (cs) LIC_GB(4, true, true); else LIC_GB(4, false, true); }
+    else { if (cs) LIC_GB(4, true, false); else LIC_GB(4, false, false); }
+  }
+#undef LIC_GB
+  return lic_check_launch();
+}
+
 LIC_EXPORT int lic_gdn_bwd_bf16(const void* g, const void* x, const void* norm, const void* gamma_packed, void* dx,
                                 void* t, float* colsum_t_partial, float* colsum_dx_partial, int64_t P, int32_t C,
                                 int32_t inverse, lic_stream_t stream) {
@@ -205,15 +273,23 @@ LIC_EXPORT int lic_gdn_bwd_bf16(const void* g, const void* x, const void* norm, 
   for (const void* q : {g, x, norm, gamma_packed, (const void*)dx, (const void*)t})
     if (reinterpret_cast<uintptr_t>(q) & 15) return LIC_ERR_INVALID;
   GdnBwdHParams p{(const gb_bf16*)g, (const gb_bf16*)x, (const gb_bf16*)norm, (const gb_bf16*)gamma_packed,
-                  (gb_bf16*)dx, (gb_bf16*)t, colsum_t_partial, colsum_dx_partial, (long)P, inverse ? 1 : 0};
-  const unsigned grid = gdn_bwd_bf16_grid(P);
-  hipStream_t s = (hipStream_t)stream;
-  if (colsum_t_partial) {
-    if (C == 64) hipLaunchKernelGGL((gdn_bwd_bf16_kernel<2, true>), dim3(grid), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((gdn_bwd_bf16_kernel<4, true>), dim3(grid), dim3(256), 0, s, p);
-  } else {
-    if (C == 64) hipLaunchKernelGGL((gdn_bwd_bf16_kernel<2>), dim3(grid), dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((gdn_bwd_bf16_kernel<4>), dim3(grid), dim3(256), 0, s, p);
-  }
-  return lic_check_launch();
+                  (gb_bf16*)dx, (gb_bf16*)t, nullptr, nullptr, colsum_t_partial, colsum_dx_partial, (long)P, inverse ? 1 : 0};
+  return gdn_bwd_bf16_run(p, C, false, (hipStream_t)stream);
+}
+
+// ... with the pool recomputed instead of read: norm = beta_eff + x^2 . gamma_eff^T is formed here as the forward pass
+// forms it (x^2 and the result rounded to bf16), so the forward pass need not store it.  gammaT_packed =
+// lic_pack_weight_bf16_kperm(gamma_eff, taps 1, K = C, N = C, s_k = 1, s_n = C) (the fused forward kernels' operand).
+LIC_EXPORT int lic_gdn_bwd_bf16_recompute(const void* g, const void* x, const void* gamma_packed, const void* gammaT_packed,
+                                          const float* beta_eff, void* dx, void* t, float* colsum_t_partial,
+                                          float* colsum_dx_partial, int64_t P, int32_t C, int32_t inverse,
+                                          lic_stream_t stream) {
+  if (!g || !x || !gamma_packed || !gammaT_packed || !beta_eff || !dx || !t || P <= 0) return LIC_ERR_INVALID;
+  if ((colsum_t_partial == nullptr) != (colsum_dx_partial == nullptr)) return LIC_ERR_INVALID;
+  if (!lic_gdn_bwd_bf16_supported(C)) return LIC_ERR_UNSUPPORTED;
+  for (const void* q : {g, x, gamma_packed, gammaT_packed, (const void*)beta_eff, (const void*)dx, (const void*)t})
+    if (reinterpret_cast<uintptr_t>(q) & 15) return LIC_ERR_INVALID;
+  GdnBwdHParams p{(const gb_bf16*)g, (const gb_bf16*)x, nullptr, (const gb_bf16*)gamma_packed, (gb_bf16*)dx, (gb_bf16*)t,
+                  (const gb_bf16*)gammaT_packed, beta_eff, colsum_t_partial, colsum_dx_partial, (long)P, inverse ? 1 : 0};
+  return gdn_bwd_bf16_run(p, C, true, (hipStream_t)stream);
 }

@@ -491,6 +491,13 @@ def _gamma_eff(gamma, gamma_bound, pedestal):
     return gamma_e
 
 
+def norm_recomputed_bf16(Cc: int) -> bool:
+    """True when the GDN backward of this width recomputes the pool norm instead of reading it (lic_gdn_bwd_bf16_recompute):
+    the forward pass then does not store it"""
+    return os.environ.get("LIC_BF16_GDN_RECOMPUTE", "1") != "0" and os.environ.get("LIC_BF16_GDN_BWD", "1") != "0" and \
+        bool(L.load().lic_gdn_bwd_bf16_supported(int(Cc)))
+
+
 class _GDNBF16Fn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, beta, gamma, inverse, beta_bound, gamma_bound, pedestal, keep=True):
@@ -499,7 +506,8 @@ class _GDNBF16Fn(torch.autograd.Function):
         B, H, W, Cc = xh.shape
         beta_e, gT = _gdn_operands_bf16(beta, gamma, beta_bound, gamma_bound, pedestal)
         out = torch.empty_like(xh)
-        norm = torch.empty_like(xh) if keep else None   # (only the backward pass reads it)
+        # (only the backward pass reads it -- and not even that where it recomputes the pool)
+        norm = torch.empty_like(xh) if keep and not norm_recomputed_bf16(Cc) else None
         P = B * H * W
         _igemm_bf16(xh, gT, out, B=1, Hi=1, Wi=P, Cin=Cc, Ho=1, Wo=P, Cout=Cc, kh=1, kw=1, stride=1, pad=0,
                     transposed=False, bias=beta_e, prologue=1, epilogue=L.EPI_IGDN if inverse else L.EPI_GDN,
@@ -543,7 +551,10 @@ def _gdn_backward_bf16(xh, norm, beta, gamma, g, inverse, beta_bound, gamma_boun
     t = torch.empty_like(xh)
     dxh = dbeta = dgamma = None
     part_t = part_dx = None
-    if need_dx and lib.lic_gdn_bwd_bf16_supported(Cc) and os.environ.get("LIC_BF16_GDN_BWD", "1") != "0":
+    if norm is None and not (lib.lic_gdn_bwd_bf16_supported(Cc) and os.environ.get("LIC_BF16_GDN_BWD", "1") != "0"):
+        raise L.LicError("GDN backward without a stored norm needs the recomputing kernel (C in {64, 128}); the forward "
+                         "pass and the backward pass disagree about LIC_BF16_GDN_RECOMPUTE / LIC_BF16_GDN_BWD")
+    if (need_dx or norm is None) and lib.lic_gdn_bwd_bf16_supported(Cc) and os.environ.get("LIC_BF16_GDN_BWD", "1") != "0":
         # one sweep: g, x, norm read once, t and dx written (lic_gdn_bf16.hip); the two-launch route below moves
         # 1.8x the bytes
         dxh = torch.empty_like(xh)
@@ -559,10 +570,18 @@ def _gdn_backward_bf16(xh, norm, beta, gamma, g, inverse, beta_bound, gamma_boun
             rows = lib.lic_gdn_bwd_bf16_partial_rows(P)
             part_t = torch.empty((rows, Cc), device=xh.device, dtype=torch.float32)
             part_dx = torch.empty((rows, Cc), device=xh.device, dtype=torch.float32)
-        F_._timed(f"gdn_bwd_bf16_kernel<{Cc // 32}>", 2 * P * Cc * Cc, 10 * P * Cc,
-                  lambda: L.check(lib.lic_gdn_bwd_bf16(_ptr(g), _ptr(xh), _ptr(norm), _ptr(gp), _ptr(dxh), _ptr(t),
-                                                       _ptr(part_t), _ptr(part_dx), P, Cc, int(inverse), _stream()),
-                                  "lic_gdn_bwd_bf16"))
+        if norm is None:
+            # the forward pass did not store the pool: it is recomputed in the same sweep (two tensors read instead of three)
+            beta_e, gTp = _gdn_operands_bf16(beta, gamma, beta_bound, gamma_bound, pedestal, kperm=True)
+            F_._timed(f"gdn_bwd_bf16_kernel<{Cc // 32}>", 4 * P * Cc * Cc, 8 * P * Cc,
+                      lambda: L.check(lib.lic_gdn_bwd_bf16_recompute(_ptr(g), _ptr(xh), _ptr(gp), _ptr(gTp), _ptr(beta_e),
+                                                                     _ptr(dxh), _ptr(t), _ptr(part_t), _ptr(part_dx), P, Cc,
+                                                                     int(inverse), _stream()), "lic_gdn_bwd_bf16_recompute"))
+        else:
+            F_._timed(f"gdn_bwd_bf16_kernel<{Cc // 32}>", 2 * P * Cc * Cc, 10 * P * Cc,
+                      lambda: L.check(lib.lic_gdn_bwd_bf16(_ptr(g), _ptr(xh), _ptr(norm), _ptr(gp), _ptr(dxh), _ptr(t),
+                                                           _ptr(part_t), _ptr(part_dx), P, Cc, int(inverse), _stream()),
+                                      "lic_gdn_bwd_bf16"))
     else:
         L.check(lib.lic_gdn_dnorm_bf16(_ptr(g), _ptr(xh), _ptr(norm), _ptr(t), xh.numel(), int(inverse), _stream()),
                 "lic_gdn_dnorm_bf16")
@@ -653,7 +672,7 @@ class _ConvGDNBF16Fn(torch.autograd.Function):
                         "lic_pack_stem_weight_bf16")
             y = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=BF16)
             conv_out = torch.empty_like(y) if keep else None
-            norm = torch.empty_like(y) if keep else None
+            norm = torch.empty_like(y) if keep and not norm_recomputed_bf16(Cout) else None
             from . import functional as F_
             if F_.KERNEL_TRACE is not None:
                 F_.KERNEL_TRACE.add(f"stem_gdn_bf16_kernel<{Cout // 32}, {8 if Cout == 192 else 4}>")
@@ -677,7 +696,7 @@ class _ConvGDNBF16Fn(torch.autograd.Function):
                            transposed=transposed)
             y = torch.empty((B, Ho, Wo, Cout), device=x.device, dtype=BF16)
             conv_out = torch.empty_like(y) if keep else None
-            norm = torch.empty_like(y) if keep else None
+            norm = torch.empty_like(y) if keep and not norm_recomputed_bf16(Cout) else None
             _igemm_bf16(src, wp, y, bias=bias, epilogue=epi, aux=gT, aux2=beta_e, out2=norm, out3=conv_out, **geo)
         ctx.save_for_backward(src, weight, conv_out, norm, beta, gamma)
         ctx.cfg = (stride, pad, transposed, inverse, beta_bound, gamma_bound, pedestal, bias is not None, x.dtype, stem,

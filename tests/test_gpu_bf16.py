@@ -560,6 +560,24 @@ def test_gdn_bwd_one_sweep_bf16(env, C, P, inverse):
         assert float((got - ref).abs().max()) <= tol, (what, float((got - ref).abs().max()), tol)
     assert lib.lic_gdn_bwd_bf16(_ptr(g), _ptr(x), _ptr(nrm), _ptr(gp1), _ptr(dx3), _ptr(t3), _ptr(pt), None, P, C, 0,
                                 _stream()) == -1   # both or neither
+    # the recomputing variant (no stored norm: norm = beta + x^2 . gamma^T formed in the kernel as the forward pass forms
+    # it) against the reading variant fed with that norm: t and dx agree up to the odd bf16 flip of the recomputed norm
+    beta_e = (torch.rand(C, generator=gen) * 0.5 + 0.1).to(d)
+    sq = (x.float() ** 2).to(BF).float()
+    nrm_re = (beta_e[None, :] + sq @ gamma_e.to(BF).float().t()).to(BF)
+    gpT = FB._pack_bf16(gamma_e, 1, C, C, 0, 1, C, kperm=True)
+    dx4, t4 = torch.empty_like(x), torch.empty_like(x)
+    L.check(lib.lic_gdn_bwd_bf16(_ptr(g), _ptr(x), _ptr(nrm_re), _ptr(gp1), _ptr(dx4), _ptr(t4), None, None, P, C,
+                                 int(inverse), _stream()), "lic_gdn_bwd_bf16")
+    dx5, t5 = torch.empty_like(x), torch.empty_like(x)
+    L.check(lib.lic_gdn_bwd_bf16_recompute(_ptr(g), _ptr(x), _ptr(gp1), _ptr(gpT), _ptr(beta_e), _ptr(dx5), _ptr(t5), _ptr(pt),
+                                           _ptr(pdx), P, C, int(inverse), _stream()), "lic_gdn_bwd_bf16_recompute")
+    torch.cuda.synchronize()
+    for a5, a4, what in ((t5, t4, "t"), (dx5, dx4, "dx")):
+        a5, a4 = a5.float(), a4.float()
+        sc = float(a4.abs().max())
+        assert float((a5 - a4).abs().max()) <= 2.0 ** -5 * sc, (what, float((a5 - a4).abs().max()), sc)
+        assert float(((a5 - a4).abs() > 2.0 ** -9 * sc).float().mean()) < 0.02, what
     # unsupported widths and misaligned pointers are refused, not mis-run
     assert lib.lic_gdn_bwd_bf16(_ptr(g), _ptr(x), _ptr(nrm), _ptr(gp1), _ptr(dx1), _ptr(t1), None, None, P, 192, 0, _stream()) \
         == -2   # LIC_ERR_UNSUPPORTED
