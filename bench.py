@@ -102,7 +102,7 @@ def cpu_baseline(M, K, H, W, lam, budget_s=25.0):
             "c_oracle_images_per_s": round(c_ips, 4)}
 
 
-def analysis_hyperprior_fwd(model, x, F_, bf16, reps=5):
+def analysis_hyperprior_fwd(model, x, F_, bf16, reps=5, planned=False):
     """Forward of everything but the synthesis transform (the north star's target scope), timed
     apart from the K steps: wall time of `reps` passes, algorithmic FLOP / bytes from the launch
     plans of its MFMA kernels, and the roofline time max(t_flop, t_hbm) summed per launch."""
@@ -119,6 +119,22 @@ def analysis_hyperprior_fwd(model, x, F_, bf16, reps=5):
         model.analysis_hyperprior(x)
         torch.cuda.synchronize()
         prof, F_.PROFILE = F_.PROFILE, None
+    planned_ms = None
+    if planned:
+        # the same forward captured once and replayed by the library (plan.ForwardPlan): what the GPU needs when Python is
+        # not between the launches (the eager figure above is host-paced in the bf16 configurations: ~23 launches x ~20 us)
+        from neural_image_compression_amd.plan import ForwardPlan
+        fp = ForwardPlan(model, x)
+        for _ in range(3):
+            fp(x)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(4 * reps):
+            fp(x)
+        torch.cuda.synchronize()
+        planned_ms = (time.perf_counter() - t0) / (4 * reps) * 1e3
+        planned_info = fp.info
+        fp.close()
     flops = sum(p[1] for p in prof)
     abytes = sum(p[2] for p in prof)
     t_roof = sum(max(p[1] / ((BF16_MFMA_PEAK_TF if "bf16" in p[0] else FP32_MFMA_PEAK_TF) * 1e12),
@@ -129,7 +145,9 @@ def analysis_hyperprior_fwd(model, x, F_, bf16, reps=5):
             "hbm_frac": round(abytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
             "mfma_frac": round(flops / (ms * 1e-3) / 1e12 / (BF16_MFMA_PEAK_TF if bf16 else FP32_MFMA_PEAK_TF), 4),
             "t_roof_ms": round(t_roof, 3), "roofline_fraction": round(t_roof / ms, 4),
-            "images_per_s": round(x.shape[0] / ms * 1e3, 1)}
+            "images_per_s": round(x.shape[0] / ms * 1e3, 1),
+            **({"planned_ms": round(planned_ms, 3), "planned_roofline_fraction": round(t_roof / planned_ms, 4),
+                "planned_launches": planned_info["kernels"]} if planned_ms is not None else {})}
 
 
 def main():
@@ -365,7 +383,7 @@ def main():
             # (sum of bracketed launches / wall time; can exceed 1: two HIP streams overlap)
             line["profiled_kernel_time_over_step_time"] = round(mfma_s / bracketed_steps / (el / args.steps), 4)
         if world == 1 and not args.no_analysis_fwd:
-            line["analysis_hyperprior_fwd"] = analysis_hyperprior_fwd(model, x, F_, bf16)
+            line["analysis_hyperprior_fwd"] = analysis_hyperprior_fwd(model, x, F_, bf16, planned=plan is not None)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(M, K, H, W, lam)

@@ -151,3 +151,75 @@ class StepPlan:
             self.close()
         except Exception:
             pass
+
+
+class ForwardPlan:
+    """The analysis + hyperprior forward (models.analysis_hyperprior: the scope BASELINE's north star quotes its roofline
+    on; also what a serving process runs before the entropy coder) captured once under no_grad and replayed by the
+    library -- StepPlan without the backward pass.  `training`: with the quantiser's uniform noise (drawn per call into a
+    fixed buffer, the reference's order) or with rounding."""
+
+    def __init__(self, model, example: torch.Tensor, training: bool = True, warmup: int = 2):
+        if not example.is_cuda:
+            raise L.LicError("ForwardPlan needs a CUDA batch (there is no CPU fallback)")
+        self.model, self.training = model, training
+        self._lib = L.load()
+        self._plan = C.c_void_p()
+        self.x = example.clone(memory_format=torch.preserve_format)
+        dev = example.device
+        gen_state = torch.cuda.get_rng_state(dev)
+        with torch.no_grad():
+            probe = model.analysis_hyperprior(self.x, training=training)
+        y, z = probe["y"], probe["z"]
+        Bn, Mc, hy, wy = y.shape
+        _, Mz, hz, wz = z.shape
+        nz, ny = Bn * hz * wz * Mz, Bn * hy * wy * Mc
+        self.u = torch.empty(nz + ny, device=dev, dtype=y.dtype)
+        self.noise = (self.u[:nz].view(Bn, hz, wz, Mz).permute(0, 3, 1, 2),
+                      self.u[nz:].view(Bn, hy, wy, Mc).permute(0, 3, 1, 2)) if training else None
+        del probe, y, z
+        self.side = model.side_stream() if hasattr(model, "side_stream") else torch.cuda.Stream(device=dev)
+        self._sides = (C.c_void_p * 1)(self.side.cuda_stream)
+        cap = torch.cuda.Stream(device=dev)
+        cap.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(cap), torch.no_grad():
+            for _ in range(max(warmup, 1)):
+                self.u.uniform_()
+                model.analysis_hyperprior(self.x, training=training, noise=self.noise)
+        torch.cuda.current_stream(dev).wait_stream(cap)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph(keep_graph=True)
+        with torch.no_grad(), torch.cuda.graph(self.graph, stream=cap):
+            self.out = model.analysis_hyperprior(self.x, training=training, noise=self.noise)
+        torch.cuda.set_rng_state(gen_state, dev)
+        rc = self._lib.lic_plan_create(C.c_void_p(self.graph.raw_cuda_graph()), C.byref(self._plan))
+        if rc != 0:
+            why = self._lib.lic_plan_last_error().decode()
+            self._plan = C.c_void_p()
+            raise L.LicError(f"lic_plan_create failed: {L._STATUS.get(rc, rc)} ({why})")
+        info = (C.c_int64 * 7)()
+        L.check(self._lib.lic_plan_info(self._plan, info), "lic_plan_info")
+        self.info = dict(zip(("nodes", "kernels", "memsets", "memcpys", "on_side_stream", "events", "tuned"), list(info)))
+
+    def __call__(self, x: torch.Tensor):
+        if x.shape != self.x.shape:
+            raise L.LicError(f"ForwardPlan was captured for batches of shape {tuple(self.x.shape)}, got {tuple(x.shape)}")
+        if x.data_ptr() != self.x.data_ptr():
+            self.x.copy_(x, non_blocking=True)
+        if self.training:
+            self.u.uniform_()
+        rc = self._lib.lic_plan_replay(self._plan, _stream(), self._sides, 1)
+        if rc != 0:
+            raise L.LicError(f"lic_plan_replay failed: {L._STATUS.get(rc, rc)} ({self._lib.lic_plan_last_error().decode()})")
+        return self.out
+
+    def close(self):
+        if self._plan:
+            self._lib.lic_plan_destroy(self._plan)
+            self._plan = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -234,3 +234,29 @@ def test_deferred_reductions_change_no_bit(precision, M, K):
         assert torch.equal(wa, wb) and torch.equal(ba, bb)
     finally:
         F_.DEFER_REDUCTIONS, F_.DEFER_FP32 = True, False
+
+
+def test_forward_plan_equals_the_eager_forward():
+    """plan.ForwardPlan (analysis + hyperprior forward, captured once, replayed by the library) against the eager call
+    from the same generator state: every output tensor bit for bit, with noise and with rounding"""
+    _need_gpu()
+    import neural_image_compression_amd as nic
+    from neural_image_compression_amd.plan import ForwardPlan
+    dev = torch.device("cuda:0")
+    torch.manual_seed(8)
+    m = nic.JointAutoregressiveHierarchical(128, 3).to(dev)
+    m.set_precision("bf16")
+    xs = [torch.rand(2, 3, 128, 128, device=dev).contiguous(memory_format=torch.channels_last) for _ in range(2)]
+    for training in (True, False):
+        fp = ForwardPlan(m, xs[0], training=training)
+        assert fp.info["kernels"] >= 15 and fp.info["memcpys"] == 0
+        for x in xs:
+            torch.cuda.manual_seed(3)
+            with torch.no_grad():
+                ref = {k: v.clone() for k, v in m.analysis_hyperprior(x, training=training).items() if torch.is_tensor(v)}
+            torch.cuda.manual_seed(3)
+            got = fp(x)
+            torch.cuda.synchronize()
+            for k, v in ref.items():
+                assert torch.equal(got[k], v), (training, k)
+        fp.close()
