@@ -35,6 +35,7 @@ struct GdnBwdHParams {
   float* cs_t;   // optional: [gridDim.x][C] per-workgroup column sums of t (-> d beta) ...
   float* cs_dx;  // ... and of dx (-> the d bias of the convolution in front); both or neither
   long P;
+  long cs_rows;  // rows of cs_t / cs_dx
   int inverse;
 };
 
@@ -89,6 +90,20 @@ __global__ __launch_bounds__(256, NT4 <= 2 ? 2 : 1) void gdn_bwd_bf16_kernel(con
   __syncthreads();
 
   const long ntile = (p.P + 127) / 128;
+  // RN: the NEXT tile's g and x are in flight while the current one is computed (a second register set, copied over at
+  // the top of the loop) -- with the pool recomputed the sweep has more arithmetic between its loads and its stores, and a
+  // wave that computes has nothing in flight
+  gb_u32x4 gN[RN ? NG : 1], xN[RN ? NG : 1];
+  auto prefetch = [&](long tile) {
+    const long row = tile * 128 + wave * 32 + li;
+    const long off = (row < p.P ? row : 0) * C + 8 * lh;
+#pragma unroll
+    for (int s = 0; s < NG; ++s) {
+      gN[RN ? s : 0] = *reinterpret_cast<const gb_u32x4*>(p.g + off + 16 * s);
+      xN[RN ? s : 0] = *reinterpret_cast<const gb_u32x4*>(p.x + off + 16 * s);
+    }
+  };
+  if (RN && (long)blockIdx.x < ntile) prefetch(blockIdx.x);
   for (long tile = blockIdx.x; tile < ntile; tile += gridDim.x) {
     // (without the column sums' wave barriers nothing stops hipcc from hoisting BOTH panels' fragments out of the loop)
     if (RN && !CS) asm volatile("" ::: "memory");
@@ -97,11 +112,20 @@ __global__ __launch_bounds__(256, NT4 <= 2 ? 2 : 1) void gdn_bwd_bf16_kernel(con
     const long off = (rok ? row : 0) * C + 8 * lh;
     // ---- one sweep: 8 consecutive channels of group s for this lane's pixel, all three streams in flight at once
     gb_u32x4 gq[NG], xq[NG], nq[NG];
+    if (RN) {
 #pragma unroll
-    for (int s = 0; s < NG; ++s) {
-      gq[s] = *reinterpret_cast<const gb_u32x4*>(p.g + off + 16 * s);
-      xq[s] = *reinterpret_cast<const gb_u32x4*>(p.x + off + 16 * s);
-      if (!RN) nq[s] = *reinterpret_cast<const gb_u32x4*>(p.norm + off + 16 * s);
+      for (int s = 0; s < NG; ++s) {
+        gq[s] = gN[RN ? s : 0];
+        xq[s] = xN[RN ? s : 0];
+      }
+      if (tile + gridDim.x < ntile) prefetch(tile + gridDim.x);
+    } else {
+#pragma unroll
+      for (int s = 0; s < NG; ++s) {
+        gq[s] = *reinterpret_cast<const gb_u32x4*>(p.g + off + 16 * s);
+        xq[s] = *reinterpret_cast<const gb_u32x4*>(p.x + off + 16 * s);
+        nq[s] = *reinterpret_cast<const gb_u32x4*>(p.norm + off + 16 * s);
+      }
     }
     auto lo = [](unsigned u) { return __builtin_bit_cast(float, u << 16); };
     auto hi = [](unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); };
@@ -231,7 +255,10 @@ __global__ __launch_bounds__(256, NT4 <= 2 ? 2 : 1) void gdn_bwd_bf16_kernel(con
       const int which = tid / C, c = tid - which * C;
       const float* q = red + which * 4 * C + c;
       const float v = (q[0] + q[C]) + (q[2 * C] + q[3 * C]);
-      (which ? p.cs_dx : p.cs_t)[(long)blockIdx.x * C + c] = v;
+      float* dstp = which ? p.cs_dx : p.cs_t;
+      dstp[(long)blockIdx.x * C + c] = v;
+      // (the caller sized the buffers for lic_gdn_bwd_bf16_partial_rows(P) rows: a smaller grid zeroes the rest)
+      for (long r = (long)blockIdx.x + gridDim.x; r < p.cs_rows; r += gridDim.x) dstp[r * C + c] = 0.0f;
     }
   }
 }
@@ -250,7 +277,19 @@ static unsigned gdn_bwd_bf16_grid(int64_t P) {
 LIC_EXPORT int64_t lic_gdn_bwd_bf16_partial_rows(int64_t P) { return P <= 0 ? 0 : (int64_t)gdn_bwd_bf16_grid(P); }
 
 static int gdn_bwd_bf16_run(const GdnBwdHParams& p, int C, bool rn, hipStream_t s) {
-  const unsigned grid = gdn_bwd_bf16_grid(p.P);
+  unsigned grid = gdn_bwd_bf16_grid(p.P);
+  if (rn) {
+    // Fewer, longer-lived workgroups let the prefetch work between more tiles: alone the 128^2 launch runs 186 / 167 / 155 /
+    // 143 us at 2048 / 1024 / 512 / 256 workgroups -- but the config-3 step does not move (9777-9814 / 9691-9739 / 9732-9763 /
+    // 9768-9770 img/s): beside the other stream's launches a 256-workgroup kernel with 100 KB of LDS owns its CUs for its
+    // whole life.  The default stays at the full grid; LIC_GDN_BWD_RN_GRID caps it.
+    static const long cap = [] {
+      const char* e = getenv("LIC_GDN_BWD_RN_GRID");
+      const long v = e ? atol(e) : 2048;
+      return v >= 64 ? v : 2048;
+    }();
+    if ((long)grid > cap) grid = (unsigned)cap;
+  }
 #define LIC_GB(nt, cs, rnv) hipLaunchKernelGGL((gdn_bwd_bf16_kernel<nt, cs, rnv>), dim3(grid), dim3(256), 0, s, p)
   const bool cs = p.cs_t != nullptr;
   if (C == 64) {
@@ -273,7 +312,8 @@ LIC_EXPORT int lic_gdn_bwd_bf16(const void* g, const void* x, const void* norm, 
   for (const void* q : {g, x, norm, gamma_packed, (const void*)dx, (const void*)t})
     if (reinterpret_cast<uintptr_t>(q) & 15) return LIC_ERR_INVALID;
   GdnBwdHParams p{(const gb_bf16*)g, (const gb_bf16*)x, (const gb_bf16*)norm, (const gb_bf16*)gamma_packed,
-                  (gb_bf16*)dx, (gb_bf16*)t, nullptr, nullptr, colsum_t_partial, colsum_dx_partial, (long)P, inverse ? 1 : 0};
+                  (gb_bf16*)dx, (gb_bf16*)t, nullptr, nullptr, colsum_t_partial, colsum_dx_partial, (long)P,
+                  (long)gdn_bwd_bf16_grid(P), inverse ? 1 : 0};
   return gdn_bwd_bf16_run(p, C, false, (hipStream_t)stream);
 }
 
@@ -290,6 +330,7 @@ LIC_EXPORT int lic_gdn_bwd_bf16_recompute(const void* g, const void* x, const vo
   for (const void* q : {g, x, gamma_packed, gammaT_packed, (const void*)beta_eff, (const void*)dx, (const void*)t})
     if (reinterpret_cast<uintptr_t>(q) & 15) return LIC_ERR_INVALID;
   GdnBwdHParams p{(const gb_bf16*)g, (const gb_bf16*)x, nullptr, (const gb_bf16*)gamma_packed, (gb_bf16*)dx, (gb_bf16*)t,
-                  (const gb_bf16*)gammaT_packed, beta_eff, colsum_t_partial, colsum_dx_partial, (long)P, inverse ? 1 : 0};
+                  (const gb_bf16*)gammaT_packed, beta_eff, colsum_t_partial, colsum_dx_partial, (long)P,
+                  (long)gdn_bwd_bf16_grid(P), inverse ? 1 : 0};
   return gdn_bwd_bf16_run(p, C, true, (hipStream_t)stream);
 }
