@@ -69,18 +69,60 @@ _PENDING_KEEP = []   # tensors they name: partial sums, outputs, parameters
 _PENDING_SEEN = set()
 
 
-def flush_reductions():
-    """launch every pending reduction (one lic_reduce_batch); autograd calls this at the end of a backward pass, on the
-    caller's stream, after that stream has been made to wait for every stream gradients were produced on"""
+_PENDING_LATE = []   # tensors of an EARLY flush on another stream: released at the end of the pass
+# flush_point active?  Only while plan.StepPlan records a step (it sets this): the replayed step gains ~1 % (9771 / 9772 vs
+# 9729 / 9642 img/s at config 3, same box); for the eager, host-paced step no gain could be measured (its run-to-run
+# spread on a shared host is larger than the effect), so it keeps the single flush at the end of the pass
+EARLY_FLUSH = os.environ.get("LIC_EARLY_FLUSH", "0") == "1"
+
+
+def flush_reductions(early_on=None):
+    """launch every pending reduction (one lic_reduce_batch).  Autograd calls this at the end of a backward pass, on the
+    caller's stream, after that stream has been made to wait for every stream gradients were produced on.
+    `early_on` (a stream; flush_point's backward): launch what is pending so far on THAT stream, after everything queued
+    on the current one -- the batched reduction holds no LDS and few registers, so unlike the weight-gradient launches it
+    does run beside the data-gradient chain that continues on the current stream.  The tensors it reads were allocated on
+    their producers' streams: they are kept until the end of the pass, where the engine orders the caller's stream behind
+    every stream of the pass."""
     if _PENDING_JOBS:
         n = len(_PENDING_JOBS)
         arr = (L.ReduceJob * n)(*_PENDING_JOBS)
         del _PENDING_JOBS[:]
         try:
-            L.check(L.load().lic_reduce_batch(arr, n, _stream()), "lic_reduce_batch")
+            if early_on is not None:
+                early_on.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(early_on):
+                    L.check(L.load().lic_reduce_batch(arr, n, _stream()), "lic_reduce_batch")
+                _PENDING_LATE.extend(_PENDING_KEEP)
+            else:
+                L.check(L.load().lic_reduce_batch(arr, n, _stream()), "lic_reduce_batch")
         finally:
             del _PENDING_KEEP[:]
-    _PENDING_SEEN.clear()
+    if early_on is None:
+        del _PENDING_LATE[:]
+        _PENDING_SEEN.clear()
+
+
+class _FlushPointFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, stream):
+        ctx.stream = stream
+        return t.view_as(t)
+
+    @staticmethod
+    def backward(ctx, g):
+        if _PENDING_JOBS and ctx.stream is not None:
+            flush_reductions(early_on=ctx.stream)
+        return g, None
+
+
+def flush_point(t: torch.Tensor, stream):
+    """identity; in the backward pass, when the gradient of `t` is complete, the reductions pending so far (those of
+    everything downstream of `t`) are launched on `stream` while the pass continues upstream of `t` on its own stream"""
+    if not (EARLY_FLUSH and DEFER_REDUCTIONS and t.requires_grad and torch.is_grad_enabled() and stream is not None) or \
+            GRAD_VIEWS:
+        return t
+    return _FlushPointFn.apply(t, stream)
 
 
 def can_defer(*params) -> bool:

@@ -66,6 +66,10 @@ class _HyperpriorContextModel(nn.Module):
         if self.use_step_prep and x.is_cuda:
             self.step_prep().run()   # one launch: every packed weight / GDN re-parametrisation of this step
         y = self.encoder(x)
+        if x.is_cuda and self.overlap_branches:
+            # backward: once dL/dy is complete the decoder's and the latent side's pending reductions start on the second
+            # stream, beside the encoder's backward chain (functional.flush_point)
+            y = F_.flush_point(y, self.side_stream())
         # bf16-storage consumers of y (hyper-encoder), y_in (decoder, context model) and z_in (hyper-decoder): their bf16
         # copies come out of the quantisation launches instead of one cast launch per consumer
         fuse = x.is_cuda and os.environ.get("LIC_QUANT_CASTS", "1") != "0"

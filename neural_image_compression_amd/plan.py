@@ -19,6 +19,7 @@ not execute: use the eager step for data-parallel training); fixed batch shape; 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Callable, Optional
 
 import torch
@@ -113,9 +114,15 @@ class StepPlan:
             e[2] = False
 
     def _body(self):
-        out = self.model(self.x, noise=self.noise)
-        res = self.loss_fn(out, self.x, self.lam, sync=False)
-        res["loss"].backward()
+        # (recorded steps launch the decoder's and the latent side's pending reductions as soon as dL/dy is complete, on the
+        # second stream: functional.flush_point -- worth ~1 % replayed, harmful eager)
+        early, F_.EARLY_FLUSH = F_.EARLY_FLUSH, os.environ.get("LIC_EARLY_FLUSH", "1") != "0"
+        try:
+            out = self.model(self.x, noise=self.noise)
+            res = self.loss_fn(out, self.x, self.lam, sync=False)
+            res["loss"].backward()
+        finally:
+            F_.EARLY_FLUSH = early
         return out, res
 
     def _eager_body(self):
