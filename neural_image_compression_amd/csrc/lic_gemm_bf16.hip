@@ -1532,7 +1532,9 @@ LIC_EXPORT int lic_reduce_batch(const lic_reduce_job* jobs, int32_t njobs, lic_s
       lic_reduce_job q = jobs[base + i];
       if (!q.src || !q.dst || q.splitk <= 0 || q.Cn <= 0 || (q.epilogue == LIC_REDUCE_EPI_REPARAM && !q.param)) return LIC_ERR_INVALID;
       if (q.kind == LIC_REDUCE_SLABS) {
-        if (q.ntaps <= 0 || q.Cm <= 0) return LIC_ERR_INVALID;
+        if (q.ntaps <= 0 || q.Cm <= 0 || q.mdiv < 0 || q.ndiv < 0) return LIC_ERR_INVALID;
+        if (q.Mvalid <= 0 || q.Mvalid > q.Cm) q.Mvalid = q.Cm;   // (0 = every row / column)
+        if (q.Nvalid <= 0 || q.Nvalid > q.Cn) q.Nvalid = q.Cn;
         q.nblocks = ew_grid((long)q.ntaps * q.Cm * q.Cn, 256);
       } else if (q.kind == LIC_REDUCE_COLUMNS) {
         q.nblocks = (q.Cn + 15) / 16;
