@@ -39,54 +39,70 @@ __global__ __launch_bounds__(256) void im2col_rgb5_bf16_kernel(const float* x, b
                                                                int Wo) {
   typedef float i2_f32x4u __attribute__((ext_vector_type(4), aligned(4)));
   typedef unsigned i2_u32x4 __attribute__((ext_vector_type(4)));
+  // a wave's 64 rows are 10 KB of CONSECUTIVE column-matrix bytes: the lanes park their 160-byte rows in LDS (16-byte slot
+  // 10 i + q of lane i: the eight lanes of a write group hit eight different slots) and the wave stores the block in linear
+  // order, ten fully coalesced 1 KB stores instead of ten stores of 64 16-byte pieces 160 bytes apart
+  __shared__ __attribute__((aligned(16))) i2_u32x4 park[4][640];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int rowf = 3 * W;
-  for (long pix = (long)blockIdx.x * 256 + threadIdx.x; pix < npix; pix += (long)gridDim.x * 256) {
-    const long t = pix / Wo;
-    const int ow = (int)(pix - t * Wo);
-    const long b = t / Ho;
-    const int oh = (int)(t - b * Ho);
-    const float* img = x + b * (long)H * rowf;
-    const int cf0 = (2 * ow - 2) * 3;                   // first of the 15 floats within an image row
-    const bool colfast = cf0 >= 0 && cf0 + 16 <= rowf;  // (16: the fourth 16-byte load reads one float too many)
-    float v[80];
+  for (long base = (long)blockIdx.x * 256 + wave * 64; base < npix; base += (long)gridDim.x * 256) {
+    const long pix = base + lane;
+    if (pix < npix) {
+      const long t = pix / Wo;
+      const int ow = (int)(pix - t * Wo);
+      const long b = t / Ho;
+      const int oh = (int)(t - b * Ho);
+      const float* img = x + b * (long)H * rowf;
+      const int cf0 = (2 * ow - 2) * 3;                   // first of the 15 floats within an image row
+      const bool colfast = cf0 >= 0 && cf0 + 16 <= rowf;  // (16: the fourth 16-byte load reads one float too many)
+      float v[80];
 #pragma unroll
-    for (int r = 0; r < 5; ++r) {
-      const int ih = 2 * oh - 2 + r;
-      const bool rowok = ih >= 0 && ih < H;
-      const float* src = img + (long)(rowok ? ih : 0) * rowf;
-      if (colfast) {
+      for (int r = 0; r < 5; ++r) {
+        const int ih = 2 * oh - 2 + r;
+        const bool rowok = ih >= 0 && ih < H;
+        const float* src = img + (long)(rowok ? ih : 0) * rowf;
+        if (colfast) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const i2_f32x4u w4 = *reinterpret_cast<const i2_f32x4u*>(src + cf0 + 4 * q);
+          for (int q = 0; q < 4; ++q) {
+            const i2_f32x4u w4 = *reinterpret_cast<const i2_f32x4u*>(src + cf0 + 4 * q);
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (4 * q + e < 15) v[15 * r + 4 * q + e] = rowok ? w4[e] : 0.0f;
-        }
-      } else {  // image border: element-wise, zero outside
+            for (int e = 0; e < 4; ++e)
+              if (4 * q + e < 15) v[15 * r + 4 * q + e] = rowok ? w4[e] : 0.0f;
+          }
+        } else {  // image border: element-wise, zero outside
 #pragma unroll
-        for (int j = 0; j < 15; ++j) {
-          const int c = cf0 + j;
-          const bool ok = rowok && c >= 0 && c < rowf;
-          const float tv = src[ok ? c : 0];
-          v[15 * r + j] = ok ? tv : 0.0f;
+          for (int j = 0; j < 15; ++j) {
+            const int c = cf0 + j;
+            const bool ok = rowok && c >= 0 && c < rowf;
+            const float tv = src[ok ? c : 0];
+            v[15 * r + j] = ok ? tv : 0.0f;
+          }
         }
       }
-    }
 #pragma unroll
-    for (int j = 75; j < 80; ++j) v[j] = 0.0f;
-    i2_u32x4* dst = reinterpret_cast<i2_u32x4*>(col + pix * 80);
+      for (int j = 75; j < 80; ++j) v[j] = 0.0f;
+#pragma unroll
+      for (int q = 0; q < 10; ++q) {
+        i2_u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          typedef float i2_f32x2 __attribute__((ext_vector_type(2)));
+          typedef bf16_t i2_bf16x2 __attribute__((ext_vector_type(2)));
+          const i2_f32x2 pr = {v[8 * q + 2 * e], v[8 * q + 2 * e + 1]};
+          o[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(pr, i2_bf16x2));
+        }
+        park[wave][10 * lane + q] = o;
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const long rows = npix - base < 64 ? npix - base : 64;   // rows of this block that exist
+    i2_u32x4* dst = reinterpret_cast<i2_u32x4*>(col + base * 80);
 #pragma unroll
     for (int q = 0; q < 10; ++q) {
-      i2_u32x4 o;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        typedef float i2_f32x2 __attribute__((ext_vector_type(2)));
-        typedef bf16_t i2_bf16x2 __attribute__((ext_vector_type(2)));
-        const i2_f32x2 pr = {v[8 * q + 2 * e], v[8 * q + 2 * e + 1]};
-        o[e] = __builtin_bit_cast(unsigned, __builtin_convertvector(pr, i2_bf16x2));
-      }
-      dst[q] = o;
+      const int slot = 64 * q + lane;
+      if (slot < 10 * rows) dst[slot] = park[wave][slot];
     }
+    __builtin_amdgcn_wave_barrier();
   }
 }
 
