@@ -103,18 +103,22 @@ __device__ void pp_map(const lic_prep_job& j, int blk) {
 // (16-k chunk, 8 columns) stages its source block through LDS with 16-byte loads along the contiguous
 // direction and writes 128-byte pieces of the packed layout.  RUN_K: for a fixed n the (k, tap) run is
 // contiguous (s_k == taps); else for a fixed k the (n, tap) run is (s_n == taps).
-template <bool RUN_K>
+// HALF: the bf16 layout (32-k chunks: dst[tap][chunk][n/32][kstep][lane][8]) from the same staged block -- the element-wise
+// bf16 packer read its source 4 bytes at a time, 100 bytes apart (57 us for the 29 MB of config 3's weights, in front of
+// the first launch of every step).
+template <bool RUN_K, bool HALF = false>
 __device__ void pp_pack_tiled(const lic_prep_job& j, int blk, float* st) {
+  constexpr int TBK = HALF ? PP_HBK : PP_BK;   // k depth of the staged block = one packed chunk
   const float* src = j.src;
   float* dst = (float*)j.dst;
   const int taps = j.taps, K = j.K, N = j.N, cpt = j.cpt, ntile = j.npad >> 5;
   const long s_k = j.s_kq, s_n = j.s_nq;
   const int cb = blk % cpt, nb = blk / cpt;
-  const int k0 = cb * PP_BK, n0 = nb * PP_NS;
-  const int run = (RUN_K ? PP_BK : PP_NS) * taps, total = PP_BK * PP_NS * taps;
+  const int k0 = cb * TBK, n0 = nb * PP_NS;
+  const int run = (RUN_K ? TBK : PP_NS) * taps, total = TBK * PP_NS * taps;
   const bool v4 = j.v4 != 0;
   if (v4 && n0 >= N) {
-    for (int i = threadIdx.x; i < taps * PP_BK * (PP_NS + 1); i += 256) st[i] = 0.0f;
+    for (int i = threadIdx.x; i < taps * TBK * (PP_NS + 1); i += 256) st[i] = 0.0f;
   } else if (v4) {
     for (int base = threadIdx.x; base < total / 4; base += 4 * 256) {
       f32x4 v[4];
@@ -138,7 +142,7 @@ __device__ void pp_pack_tiled(const lic_prep_job& j, int blk, float* st) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const int kl = RUN_K ? i : oo[u], nl = RUN_K ? oo[u] : i;
-            st[(tap * PP_BK + kl) * (PP_NS + 1) + nl] = v[u][e];
+            st[(tap * TBK + kl) * (PP_NS + 1) + nl] = v[u][e];
             if (++tap == taps) {
               tap = 0;
               ++i;
@@ -159,7 +163,7 @@ __device__ void pp_pack_tiled(const lic_prep_job& j, int blk, float* st) {
           const int o = idx / run, jx = idx - o * run;
           const int i = jx / taps, tap = jx - i * taps;
           const int kl = RUN_K ? i : o, nl = RUN_K ? o : i;
-          slot[u] = (tap * PP_BK + kl) * (PP_NS + 1) + nl;
+          slot[u] = (tap * TBK + kl) * (PP_NS + 1) + nl;
           if (k0 + kl < K && n0 + nl < N)
             v[u] = RUN_K ? src[(long)(n0 + nl) * s_n + (long)k0 * taps + jx] : src[(long)(k0 + kl) * s_k + (long)n0 * taps + jx];
         }
@@ -171,18 +175,33 @@ __device__ void pp_pack_tiled(const lic_prep_job& j, int blk, float* st) {
   }
   __syncthreads();
   const int tile = n0 >> 5, nin = n0 & 31;
+  if constexpr (HALF) {
+    typedef __bf16 pp_bf16x8 __attribute__((ext_vector_type(8)));
+    typedef float pp_f32x8 __attribute__((ext_vector_type(8)));
+    bf16_t* dh = (bf16_t*)j.dst;
+    for (int idx = threadIdx.x; idx < taps * 32; idx += 256) {   // (tap, kstep q, lane half lh, column nl): 8 k each
+      const int tap = idx >> 5, r = idx & 31, q = r >> 4, lh = (r >> 3) & 1, nl = r & 7;
+      const int kl = q * 16 + lh * 8, lane = lh * 32 + nin + nl;
+      pp_f32x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = st[(tap * TBK + kl + e) * (PP_NS + 1) + nl];
+      *reinterpret_cast<pp_bf16x8*>(dh + ((((long)tap * cpt + cb) * ntile + tile) * 2 + q) * 512 + lane * 8) =
+          __builtin_convertvector(o, pp_bf16x8);
+    }
+    return;
+  }
   for (int idx = threadIdx.x; idx < taps * 32; idx += 256) {
     const int tap = idx >> 5, r = idx & 31, q = r >> 4, lh = (r >> 3) & 1, nl = r & 7;
     const int kl = lh * 8 + q * 4, lane = lh * 32 + nin + nl;
     f32x4 o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = st[(tap * PP_BK + kl + e) * (PP_NS + 1) + nl];
+    for (int e = 0; e < 4; ++e) o[e] = st[(tap * TBK + kl + e) * (PP_NS + 1) + nl];
     *reinterpret_cast<f32x4*>(dst + (((long)tap * cpt + cb) * ntile + tile) * 512 + q * 256 + lane * 4) = o;
   }
 }
 
 __global__ __launch_bounds__(256) void prep_kernel(const lic_prep_job* jobs, int njobs) {
-  __shared__ __attribute__((aligned(16))) float st[PP_MAXTAPS * PP_BK * (PP_NS + 1)];
+  __shared__ __attribute__((aligned(16))) float st[PP_MAXTAPS * PP_HBK * (PP_NS + 1)];
   __shared__ lic_prep_job job;
   __shared__ int s_blk;
   if (threadIdx.x == 0) {
@@ -205,7 +224,9 @@ __global__ __launch_bounds__(256) void prep_kernel(const lic_prep_job* jobs, int
     else if (job.tiled == 2) pp_pack_tiled<false>(job, blk, st);
     else pp_pack_f32(job, blk);
   } else if (job.kind == LIC_PREP_PACK_BF16 || job.kind == LIC_PREP_PACK_BF16_KPERM || job.kind == LIC_PREP_PACK_BF16_STEM) {
-    pp_pack_bf16(job, blk);
+    if (job.tiled == 1) pp_pack_tiled<true, true>(job, blk, st);
+    else if (job.tiled == 2) pp_pack_tiled<false, true>(job, blk, st);
+    else pp_pack_bf16(job, blk);
   } else {
     pp_map(job, blk);
   }
@@ -239,9 +260,14 @@ LIC_EXPORT int64_t lic_prep_plan(lic_prep_job* jobs, int32_t njobs) {
       j.total = (long)j.taps * j.cpt * j.npad * bk;
       const long s_k = j.s_kq, s_n = j.s_nq;
       const bool plain = j.kdiv == 0 && j.ndiv == 0 && j.transform == 0 && j.mask == nullptr;
-      if (!h && plain && j.s_tap == 1 && j.taps >= 4 && j.taps <= PP_MAXTAPS && (s_k == j.taps || s_n == j.taps)) {
+      static const bool tiled_h = [] {
+        const char* e = getenv("LIC_PREP_TILED_BF16");
+        return !(e && e[0] == '0');
+      }();
+      if ((!h || (j.kind == LIC_PREP_PACK_BF16 && tiled_h)) && plain && j.s_tap == 1 && j.taps >= 4 && j.taps <= PP_MAXTAPS &&
+          (s_k == j.taps || s_n == j.taps)) {
         j.tiled = (s_k == j.taps) ? 1 : 2;
-        j.v4 = (j.K % PP_BK == 0 && j.N % PP_NS == 0 && pp_al16(j.src) && ((s_k == j.taps ? s_n : s_k) % 4 == 0)) ? 1 : 0;
+        j.v4 = (j.K % bk == 0 && j.N % PP_NS == 0 && pp_al16(j.src) && ((s_k == j.taps ? s_n : s_k) % 4 == 0)) ? 1 : 0;
         j.nblocks = j.cpt * (j.npad / PP_NS);
       } else {
         j.nblocks = (int)((j.total + PP_ITEMS - 1) / PP_ITEMS);
