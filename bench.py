@@ -250,8 +250,12 @@ def main():
         from neural_image_compression_amd.plan import StepPlan
         plan = StepPlan(model, nic.rd_loss, lam, x, tune=os.environ.get("LIC_PLAN_TUNE") == "1")
 
+        # the synthetic batch is resident in the plan's input buffer (where a data pipeline deposits its H2D copy: the
+        # eager step reads `x` in place too; handing `x` itself over would add a 25 MB device copy per step)
+        plan.x.copy_(x)
+
         def step():
-            _, res = plan.step(x)
+            _, res = plan.step(plan.x)
             opt.step()
             return res
 
