@@ -525,6 +525,12 @@ int lic_colsum_bf16_partial(const void* in, int64_t ld, int64_t P, int32_t C, fl
 int lic_colsum2_bf16_partial(const void* in_a, const void* in_b, int64_t ld, int64_t P, int32_t C, float scale,
                              float* out_a, float* out_b, void* workspace, size_t workspace_bytes, lic_reduce_job* jobs2,
                              lic_stream_t stream);
+/* lic_leaky_bwd_bf16 on [P][C] matrices, with the column sums of dx (the bias gradient of the convolution in front of the LeakyReLU:
+ * Components.py:69-73,99-103, ParametersModels.py:22-34) out of the same pass.  workspace: lic_colsum_bf16_workspace_bytes(P, C);
+ * `job` NULL: out[C] is complete when the call's launches are; else the sums' second stage is left in *job for
+ * lic_reduce_batch.  Same bits as lic_leaky_bwd_bf16 followed by lic_colsum_bf16 / lic_colsum_bf16_partial. */
+int lic_leaky_bwd_colsum_bf16(const void* y, const void* dy, void* dx, int64_t P, int32_t C, float slope, float* out,
+                              void* workspace, size_t workspace_bytes, lic_reduce_job* job, lic_stream_t stream);
 int lic_reduce_batch(const lic_reduce_job* jobs, int32_t njobs, lic_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------

@@ -143,6 +143,7 @@ SIGNATURES = {
     "lic_gdn_bwd_bf16": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "lic_gdn_bwd_bf16_recompute": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp]),
     "lic_leaky_bwd_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _vp]),
+    "lic_leaky_bwd_colsum_bf16": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _vp, _vp, _sz, C.POINTER(ReduceJob), _vp]),
     "lic_igemm_fused_gdn_supported": (C.c_int, [_i32, _i32]),
     "lic_igemm_fused_gdn_preferred": (C.c_int, [C.POINTER(IgemmDesc)]),
     "lic_gdn_supported": (C.c_int, [_i32]),

@@ -178,8 +178,13 @@ LIC_EXPORT int lic_col2im_bf16(const void* col, const float* bias, float* out, i
 
 // column sums of a bf16 [P][ld] matrix -> fp32, two deterministic stages (C % 8 == 0)
 // (blockIdx.z = 1: the second matrix of lic_colsum2_bf16 -- same shape, its partials behind the first's)
+// MASKED (lic_leaky_bwd_colsum_bf16): `in` = dy goes through the LeakyReLU's backward first -- v = y > 0 ? dy : bf16(dy *
+// slope), leaky_bwd_bf16_kernel's arithmetic -- is written to `gout` and summed: the bias gradient of a conv -> LeakyReLU
+// layer in the pass that masks its gradient (every element is visited exactly once), instead of a pass of its own.
+template <bool MASKED>
 __global__ __launch_bounds__(256) void colsum_bf16_stage1(const bf16_t* in, const bf16_t* in2, long ld, long P, int C,
-                                                          float* part, int nchunk) {
+                                                          float* part, int nchunk, const bf16_t* ymask, bf16_t* gout,
+                                                          float slope) {
   __shared__ float red[32][64 + 4];
   if (blockIdx.z) {
     in = in2;
@@ -190,7 +195,13 @@ __global__ __launch_bounds__(256) void colsum_bf16_stage1(const bf16_t* in, cons
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (c < C)
     for (long pr = (long)blockIdx.y * 32 + ry; pr < P; pr += (long)nchunk * 32) {
-      const bf16x8 v = *reinterpret_cast<const bf16x8*>(in + pr * ld + c);
+      bf16x8 v = *reinterpret_cast<const bf16x8*>(in + pr * ld + c);
+      if constexpr (MASKED) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(ymask + pr * ld + c);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (float)a[e] > 0.0f ? v[e] : (bf16_t)((float)v[e] * slope);
+        *reinterpret_cast<bf16x8*>(gout + pr * ld + c) = v;
+      }
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
     }
@@ -243,8 +254,8 @@ LIC_EXPORT int lic_colsum_bf16(const void* in, int64_t ld, int64_t P, int32_t C,
   const int nchunk = csh_chunks(P);
   if (workspace_bytes < (size_t)nchunk * C * sizeof(float)) return LIC_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(colsum_bf16_stage1, dim3((C + 63) / 64, nchunk), dim3(256), 0, s, (const bf16_t*)in,
-                     (const bf16_t*)nullptr, (long)ld, (long)P, C, (float*)workspace, nchunk);
+  hipLaunchKernelGGL(colsum_bf16_stage1<false>, dim3((C + 63) / 64, nchunk), dim3(256), 0, s, (const bf16_t*)in,
+                     (const bf16_t*)nullptr, (long)ld, (long)P, C, (float*)workspace, nchunk, (const bf16_t*)nullptr, (bf16_t*)nullptr, 0.0f);
   int rc = lic_check_launch();
   if (rc != LIC_OK) return rc;
   hipLaunchKernelGGL(colsum_bf16_stage2, dim3((C + 15) / 16), dim3(256), 0, s, (const float*)workspace, C, nchunk,
@@ -294,8 +305,8 @@ LIC_EXPORT int lic_colsum_bf16_partial(const void* in, int64_t ld, int64_t P, in
   if (C % 8 || ld % 8 || (reinterpret_cast<uintptr_t>(in) & 15)) return LIC_ERR_UNSUPPORTED;
   const int nchunk = csh_chunks(P);
   if (workspace_bytes < (size_t)nchunk * C * sizeof(float)) return LIC_ERR_WORKSPACE;
-  hipLaunchKernelGGL(colsum_bf16_stage1, dim3((C + 63) / 64, nchunk), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in,
-                     (const bf16_t*)nullptr, (long)ld, (long)P, C, (float*)workspace, nchunk);
+  hipLaunchKernelGGL(colsum_bf16_stage1<false>, dim3((C + 63) / 64, nchunk), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)in,
+                     (const bf16_t*)nullptr, (long)ld, (long)P, C, (float*)workspace, nchunk, (const bf16_t*)nullptr, (bf16_t*)nullptr, 0.0f);
   *job = lic_reduce_job{};
   job->src = (const float*)workspace;
   job->dst = out;
@@ -313,8 +324,8 @@ LIC_EXPORT int lic_colsum2_bf16_partial(const void* in_a, const void* in_b, int6
     return LIC_ERR_UNSUPPORTED;
   const int nchunk = csh_chunks(P);
   if (workspace_bytes < 2 * (size_t)nchunk * C * sizeof(float)) return LIC_ERR_WORKSPACE;
-  hipLaunchKernelGGL(colsum_bf16_stage1, dim3((C + 63) / 64, nchunk, 2), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)in_a, (const bf16_t*)in_b, (long)ld, (long)P, C, (float*)workspace, nchunk);
+  hipLaunchKernelGGL(colsum_bf16_stage1<false>, dim3((C + 63) / 64, nchunk, 2), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)in_a, (const bf16_t*)in_b, (long)ld, (long)P, C, (float*)workspace, nchunk, (const bf16_t*)nullptr, (bf16_t*)nullptr, 0.0f);
   for (int k = 0; k < 2; ++k) {
     jobs2[k] = lic_reduce_job{};
     jobs2[k].src = (const float*)workspace + (k ? (long)nchunk * C : 0L);
@@ -336,8 +347,8 @@ LIC_EXPORT int lic_colsum2_bf16(const void* in_a, const void* in_b, int64_t ld, 
   const int nchunk = csh_chunks(P);
   if (workspace_bytes < 2 * (size_t)nchunk * C * sizeof(float)) return LIC_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(colsum_bf16_stage1, dim3((C + 63) / 64, nchunk, 2), dim3(256), 0, s, (const bf16_t*)in_a,
-                     (const bf16_t*)in_b, (long)ld, (long)P, C, (float*)workspace, nchunk);
+  hipLaunchKernelGGL(colsum_bf16_stage1<false>, dim3((C + 63) / 64, nchunk, 2), dim3(256), 0, s, (const bf16_t*)in_a,
+                     (const bf16_t*)in_b, (long)ld, (long)P, C, (float*)workspace, nchunk, (const bf16_t*)nullptr, (bf16_t*)nullptr, 0.0f);
   int rc = lic_check_launch();
   if (rc != LIC_OK) return rc;
   hipLaunchKernelGGL(colsum_bf16_stage2, dim3((C + 15) / 16, 1, 2), dim3(256), 0, s, (const float*)workspace, C, nchunk,
@@ -390,5 +401,35 @@ LIC_EXPORT int lic_leaky_bwd_bf16(const void* y, const void* dy, void* dx, int64
   if (n == 0) return LIC_OK;
   hipLaunchKernelGGL(leaky_bwd_bf16_kernel, dim3(ew_grid(n / 8, 256)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)y, (const bf16_t*)dy, (bf16_t*)dx, (long)(n / 8), slope);
+  return lic_check_launch();
+}
+// lic_leaky_bwd_bf16 on [P][C] matrices AND the column sums of its result (the bias gradient of the layer in front of the
+// LeakyReLU) in one pass.  `job` NULL: the sums' second stage follows at once (lic_colsum_bf16's); else it is left in *job for
+// lic_reduce_batch (lic_colsum_bf16_partial's).  Same bits as lic_leaky_bwd_bf16 followed by lic_colsum_bf16.
+LIC_EXPORT int lic_leaky_bwd_colsum_bf16(const void* y, const void* dy, void* dx, int64_t P, int32_t C, float slope, float* out,
+                                         void* workspace, size_t workspace_bytes, lic_reduce_job* job, lic_stream_t stream) {
+  if (!y || !dy || !dx || !out || !workspace || P <= 0 || C <= 0) return LIC_ERR_INVALID;
+  if (C % 8 || ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15))
+    return LIC_ERR_UNSUPPORTED;
+  const int nchunk = csh_chunks(P);
+  if (workspace_bytes < (size_t)nchunk * C * sizeof(float)) return LIC_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(colsum_bf16_stage1<true>, dim3((C + 63) / 64, nchunk), dim3(256), 0, s, (const bf16_t*)dy,
+                     (const bf16_t*)nullptr, (long)C, (long)P, C, (float*)workspace, nchunk, (const bf16_t*)y, (bf16_t*)dx,
+                     slope);
+  int rc = lic_check_launch();
+  if (rc != LIC_OK) return rc;
+  if (job) {
+    *job = lic_reduce_job{};
+    job->src = (const float*)workspace;
+    job->dst = out;
+    job->kind = LIC_REDUCE_COLUMNS;
+    job->splitk = nchunk;
+    job->Cn = C;
+    job->scale = 1.0f;
+    return LIC_OK;
+  }
+  hipLaunchKernelGGL(colsum_bf16_stage2, dim3((C + 15) / 16), dim3(256), 0, s, (const float*)workspace, C, nchunk, 1.0f, out,
+                     (float*)nullptr);
   return lic_check_launch();
 }

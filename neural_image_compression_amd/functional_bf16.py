@@ -227,6 +227,26 @@ def _leaky_bwd_bf16(y, dy, slope):
     return dx
 
 
+# the bias gradient of a conv -> LeakyReLU layer out of the pass that masks its gradient (LIC_BF16_LEAKY_COLSUM=0: two passes)
+LEAKY_COLSUM = os.environ.get("LIC_BF16_LEAKY_COLSUM", "1") != "0"
+
+
+def _leaky_bwd_colsum_bf16(y, dy, slope, P, Cc, defer=False):
+    """(dy through the LeakyReLU's backward, its column sums): _leaky_bwd_bf16 + _colsum_bf16 in one pass, the same bits"""
+    lib = L.load()
+    dx = torch.empty_like(y)
+    nbytes = lib.lic_colsum_bf16_workspace_bytes(P, Cc)
+    ws = torch.empty((nbytes + 3) // 4, device=y.device, dtype=torch.float32)
+    out = torch.empty((Cc,), device=y.device, dtype=torch.float32)
+    job = L.ReduceJob() if defer else None
+    L.check(lib.lic_leaky_bwd_colsum_bf16(_ptr(y), _ptr(dy), _ptr(dx), P, Cc, slope, _ptr(out), _ptr(ws), nbytes,
+                                          C.byref(job) if defer else None, _stream()), "lic_leaky_bwd_colsum_bf16")
+    if defer:
+        from . import functional as F_
+        F_.defer(job, ws)
+    return dx, out
+
+
 class _ConvBF16Fn(torch.autograd.Function):
     """nn.Conv2d / nn.ConvTranspose2d with bf16 activations (Components.py:12-16,39-43), optionally with the
     LeakyReLU behind it fused (hyper / entropy-parameter layers: Components.py:69-73,99-103;
@@ -267,31 +287,38 @@ class _ConvBF16Fn(torch.autograd.Function):
         xh, weight, yh = ctx.saved_tensors
         stride, pad, transposed, has_bias, in_dtype, leaky, slope, tap_mask = ctx.cfg
         g = _as_bf16_nhwc(gy)
-        if leaky:
-            g = _leaky_bwd_bf16(yh, g, slope)
         need = ctx.needs_input_grad
         dx, dw, db = _conv_backward_bf16(xh, weight, g, stride, pad, transposed, in_dtype, tap_mask, need[0], need[1],
-                                         has_bias and need[2])
+                                         has_bias and need[2], leaky_y=yh if leaky else None, slope=slope)
         return dx, dw, db, None, None, None, None, None, None, None, None, None
 
 
-def _conv_backward_bf16(xh, weight, g, stride, pad, transposed, in_dtype, tap_mask, need_dx, need_dw, need_db):
-    """input / weight / bias gradients of a bf16-storage convolution from g = dL/d(conv output), bf16 NHWC"""
+def _conv_backward_bf16(xh, weight, g, stride, pad, transposed, in_dtype, tap_mask, need_dx, need_dw, need_db,
+                        leaky_y=None, slope=0.01):
+    """input / weight / bias gradients of a bf16-storage convolution from g = dL/d(conv output), bf16 NHWC.
+    `leaky_y`: the layer's output went through a fused LeakyReLU (that output): g is the gradient behind it and passes
+    the LeakyReLU's backward first -- in the same pass as the bias sum when there is one"""
     B, Hi, Wi, Cin = xh.shape
     _, Ho, Wo, Cout = g.shape
     kh, kw = weight.shape[2], weight.shape[3]
     taps = kh * kw
     dx = dw = db = None
+    from . import functional as F_
+    # the slab reduction of the weight gradient and the second stage of the bias sum wait for the end of the backward
+    # pass when nothing can read these gradients earlier (functional.can_defer): one batched launch instead of ~40
+    dfr = (need_dw or need_db) and F_.can_defer(weight)
+    if leaky_y is not None:
+        if need_db and LEAKY_COLSUM and Cout % 8 == 0 and g.is_contiguous() and leaky_y.is_contiguous():
+            g, db = _leaky_bwd_colsum_bf16(leaky_y, g, slope, B * Ho * Wo, Cout, defer=dfr)
+            need_db = False
+        else:
+            g = _leaky_bwd_bf16(leaky_y, g, slope)
     if need_dx:
         wp = _pack_conv_weight_bf16(weight, transposed, True)
         dxh = torch.empty((B, Hi, Wi, Cin), device=g.device, dtype=in_dtype)
         _igemm_bf16(g, wp, dxh, B=B, Hi=Ho, Wi=Wo, Cin=Cout, Ho=Hi, Wo=Wi, Cout=Cin, kh=kh, kw=kw, stride=stride,
                     pad=pad, transposed=not transposed, tap_mask=tap_mask)
         dx = _nchw_view(dxh)
-    # the slab reduction of the weight gradient and the second stage of the bias sum wait for the end of the backward
-    # pass when nothing can read these gradients earlier (functional.can_defer): one batched launch instead of ~40
-    from . import functional as F_
-    dfr = (need_dw or need_db) and F_.can_defer(weight)
     if need_dw:
         dw = grad_like(weight)
         job = L.ReduceJob() if dfr else None

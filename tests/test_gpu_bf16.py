@@ -377,6 +377,46 @@ def _conv_bf16_ops(env, k, s, p, ci, co, H, W, B, tr, op):
     bf16_close(host(ybf), y_ref, "y (bf16 out)")
 
 
+@pytest.mark.parametrize("P,Cc", [(1000, 72), (37, 640), (8192, 128), (1, 8)])
+@pytest.mark.parametrize("deferred", [False, True])
+def test_leaky_backward_with_bias_sum_in_one_pass(env, P, Cc, deferred):
+    """lic_leaky_bwd_colsum_bf16 (the gradient of a conv -> LeakyReLU layer, Components.py:69-73 / ParametersModels.py:22-34,
+    masked and column-summed in one pass) = lic_leaky_bwd_bf16 followed by lic_colsum_bf16, bit for bit; `deferred`: the
+    sums' second stage through lic_reduce_batch"""
+    nic, FB, O, d = env
+    import ctypes as C
+    from neural_image_compression_amd import _lib as L
+    lib = L.load()
+    g = torch.Generator(device="cpu").manual_seed(P + Cc)
+    y = torch.randn(P, Cc, generator=g).to(d).to(BF)
+    dy = torch.randn(P, Cc, generator=g).to(d).to(BF)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    ptr = lambda t: C.c_void_p(t.data_ptr())
+    nbytes = lib.lic_colsum_bf16_workspace_bytes(P, Cc)
+    # two passes
+    dx_ref = torch.empty_like(y)
+    L.check(lib.lic_leaky_bwd_bf16(ptr(y), ptr(dy), ptr(dx_ref), y.numel(), 0.01, st), "leaky")
+    ws = torch.empty((nbytes + 3) // 4, device=d)
+    db_ref = torch.empty(Cc, device=d)
+    L.check(lib.lic_colsum_bf16(ptr(dx_ref), Cc, P, Cc, 1.0, ptr(db_ref), ptr(ws), nbytes, st), "colsum")
+    # one pass
+    dx = torch.full_like(y, float("nan"))
+    ws2 = torch.empty((nbytes + 3) // 4, device=d)
+    db = torch.full((Cc,), float("nan"), device=d)
+    job = L.ReduceJob()
+    L.check(lib.lic_leaky_bwd_colsum_bf16(ptr(y), ptr(dy), ptr(dx), P, Cc, 0.01, ptr(db), ptr(ws2), nbytes,
+                                          C.byref(job) if deferred else None, st), "fused")
+    if deferred:
+        L.check(lib.lic_reduce_batch(C.byref(job), 1, st), "reduce")
+    torch.cuda.synchronize()
+    assert torch.equal(dx.view(torch.int16), dx_ref.view(torch.int16))
+    assert torch.equal(db.view(torch.int32), db_ref.view(torch.int32))
+    # and against plain arithmetic on the same bf16 values
+    ref = torch.where(y.float() > 0, dy.float(), (dy.float() * 0.01).to(BF).float())
+    assert torch.equal(dx.float(), ref)
+    assert torch.allclose(db.cpu().double(), ref.double().sum(0).cpu(), rtol=1e-5, atol=1e-4 * max(1.0, P ** 0.5))
+
+
 def test_image_layers_bf16(env):
     nic, FB, O, d = env
     r = np.random.RandomState(3)
