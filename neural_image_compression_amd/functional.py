@@ -37,6 +37,9 @@ GRAD_VIEWS = {}
 # (id(parameter), kind) -> (parameter version, derived buffer, weakref): packed weights, GDN re-parametrisations
 # ... refreshed once per optimizer step by prep.StepPrep (one lic_prep_run launch); see `prepared`
 PREPARED = {}
+# a second stream the layers may put work on that nothing downstream waits for soon (models.py sets it around the encoder
+# when the model overlaps its branches; None otherwise): functional_bf16's early stem columns
+AUX_STREAM = None
 
 
 # ------------------------------------------------------------------------------------------

@@ -227,6 +227,8 @@ def _leaky_bwd_bf16(y, dy, slope):
     return dx
 
 
+# the stem's column matrix for its weight gradient built beside the forward pass (functional.AUX_STREAM; 0: in the backward pass)
+EARLY_STEM_COLUMNS = os.environ.get("LIC_EARLY_STEM_COLUMNS", "1") != "0"
 # the bias gradient of a conv -> LeakyReLU layer out of the pass that masks its gradient (LIC_BF16_LEAKY_COLSUM=0: two passes)
 LEAKY_COLSUM = os.environ.get("LIC_BF16_LEAKY_COLSUM", "1") != "0"
 
@@ -725,6 +727,21 @@ class _ConvGDNBF16Fn(torch.autograd.Function):
             conv_out = torch.empty_like(y) if keep else None
             norm = torch.empty_like(y) if keep and not norm_recomputed_bf16(Cout) else None
             _igemm_bf16(src, wp, y, bias=bias, epilogue=epi, aux=gT, aux2=beta_e, out2=norm, out3=conv_out, **geo)
+        ctx.cols = None
+        if direct and keep and EARLY_STEM_COLUMNS:
+            from . import functional as F_
+            aux = F_.AUX_STREAM
+            if aux is not None:
+                # the image's column matrix (the operand of the stem's weight gradient) depends on the image alone: it is
+                # built now, on the second stream beside the next layer's forward, instead of in the tail of the backward
+                # pass where nothing else runs
+                cur = torch.cuda.current_stream()
+                aux.wait_stream(cur)
+                with torch.cuda.stream(aux):
+                    cols = _stem_columns_bf16(x, weight, stride, pad)[0]
+                    ev = aux.record_event()
+                cols.record_stream(cur)
+                ctx.cols = (cols, ev)
         ctx.save_for_backward(src, weight, conv_out, norm, beta, gamma)
         ctx.cfg = (stride, pad, transposed, inverse, beta_bound, gamma_bound, pedestal, bias is not None, x.dtype, stem,
                    Cin, direct)
@@ -741,7 +758,12 @@ class _ConvGDNBF16Fn(torch.autograd.Function):
                                                            beta_bound, gamma_bound, pedestal, True, need[3], need[4],
                                                            bias_from_dx=want_db)
         if direct and (need[1] or (has_bias and need[2])):   # src is the image: its columns for the weight gradient
-            src = _stem_columns_bf16(_nchw_view(src), weight, stride, pad)[0]
+            if ctx.cols is not None:     # built beside the forward pass
+                src, ev = ctx.cols
+                ctx.cols = None
+                torch.cuda.current_stream().wait_event(ev)
+            else:
+                src = _stem_columns_bf16(_nchw_view(src), weight, stride, pad)[0]
         # (the bias gradient = column sums of g_conv: already there when it shared d-beta's launch pair)
         if stem:
             dx = None

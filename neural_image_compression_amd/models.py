@@ -65,7 +65,11 @@ class _HyperpriorContextModel(nn.Module):
             raise RuntimeError("H and W must be multiples of 64 (phi/psi shapes must agree, Models.py:73)")
         if self.use_step_prep and x.is_cuda:
             self.step_prep().run()   # one launch: every packed weight / GDN re-parametrisation of this step
-        y = self.encoder(x)
+        F_.AUX_STREAM = self.side_stream() if (x.is_cuda and self.overlap_branches) else None
+        try:
+            y = self.encoder(x)
+        finally:
+            F_.AUX_STREAM = None
         if x.is_cuda and self.overlap_branches:
             # backward: once dL/dy is complete the decoder's and the latent side's pending reductions start on the second
             # stream, beside the encoder's backward chain (functional.flush_point)
