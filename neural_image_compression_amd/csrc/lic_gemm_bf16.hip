@@ -5,6 +5,7 @@
 // wave -- shorter than a memory round trip -- so, as in the bf16 wgrad below, the DMA runs TWO
 // chunks ahead through a ring of three LDS buffers (counted `s_waitcnt vmcnt`, raw `s_barrier`).
 #include "lic_common.h"
+#include <algorithm>
 #include <type_traits>
 
 typedef __bf16 bf16_t;
@@ -1475,13 +1476,37 @@ __global__ __launch_bounds__(256) void reduce_batch_kernel(const ReduceTable tb)
   if (q.kind == LIC_REDUCE_SLABS) {
     const long total = (long)q.ntaps * q.Cm * q.Cn;
     for (long i = (long)blk * 256 + threadIdx.x; i < total; i += (long)q.nblocks * 256) {
+      // the stand-alone kernels' association order -- slab z into partial sum z % 8 in slab order, the slabs behind the last
+      // full group of eight into sum 0, then the tree -- with the LOADS arranged: 32 slabs requested before the first add (a
+      // 512-slab job's threads went through 64 dependent round trips of 8 loads: 42 us for 21 MB, and the launch waits for
+      // its slowest block), the tail's up to 7 slabs as one round trip
       float a8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const float* sp = q.src + i;
       int z = 0;
-      for (; z + 8 <= q.splitk; z += 8) {
+      for (; z + 32 <= q.splitk; z += 32) {
+        float v[32];
 #pragma unroll
-        for (int k = 0; k < 8; ++k) a8[k] += q.src[(long)(z + k) * total + i];
+        for (int k = 0; k < 32; ++k) v[k] = sp[(long)(z + k) * total];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int k = 0; k < 8; ++k) a8[k] += v[8 * r + k];
       }
-      for (; z < q.splitk; ++z) a8[0] += q.src[(long)z * total + i];
+      for (; z + 8 <= q.splitk; z += 8) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = sp[(long)(z + k) * total];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) a8[k] += v[k];
+      }
+      if (z < q.splitk) {
+        float v[7];
+#pragma unroll
+        for (int k = 0; k < 7; ++k) v[k] = sp[(long)(z + k < q.splitk ? z + k : q.splitk - 1) * total];
+#pragma unroll
+        for (int k = 0; k < 7; ++k)
+          if (z + k < q.splitk) a8[0] += v[k];
+      }
       const float acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
       const int n = (int)(i % q.Cn);
       const long t2 = i / q.Cn;
@@ -1504,8 +1529,19 @@ __global__ __launch_bounds__(256) void reduce_batch_kernel(const ReduceTable tb)
     const int cx = threadIdx.x & 15, ly = threadIdx.x >> 4;
     const int c = blk * 16 + cx;
     double acc = 0.0;
-    if (c < q.Cn)
-      for (int y = ly; y < q.splitk; y += 16) acc += (double)q.src[(long)y * q.Cn + c];
+    if (c < q.Cn) {
+      // (same sums in the same order; eight rows' loads requested before the first add: the per-workgroup rows of the GDN
+      // backward make 2048-row jobs, 128 dependent round trips per thread as a plain loop -- 58 us for 1 MB)
+      int y = ly;
+      for (; y + 16 * 7 < q.splitk; y += 16 * 8) {
+        float v[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) v[k] = q.src[(long)(y + 16 * k) * q.Cn + c];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) acc += (double)v[k];
+      }
+      for (; y < q.splitk; y += 16) acc += (double)q.src[(long)y * q.Cn + c];
+    }
     red[ly][cx] = acc;
     __syncthreads();
     if (ly == 0 && c < q.Cn) {
@@ -1528,8 +1564,18 @@ LIC_EXPORT int lic_reduce_batch(const lic_reduce_job* jobs, int32_t njobs, lic_s
     ReduceTable tb;
     tb.n = njobs - base < LIC_REDUCE_MAX_JOBS ? njobs - base : LIC_REDUCE_MAX_JOBS;
     int blocks = 0;
-    for (int i = 0; i < tb.n; ++i) {
-      lic_reduce_job q = jobs[base + i];
+    // the launch ends with its slowest block: jobs whose threads walk the longest dependent chains (many slabs or rows, few
+    // blocks) get the lowest block numbers, so they start first and run beside the bandwidth-sized jobs instead of after them
+    int order[LIC_REDUCE_MAX_JOBS];
+    for (int i = 0; i < tb.n; ++i) order[i] = i;
+    auto depth = [&](int i) {
+      const lic_reduce_job& q = jobs[base + i];
+      return q.kind == LIC_REDUCE_COLUMNS ? (long)q.splitk * 2 : (long)q.splitk;   // (a column thread adds doubles, one row in 16)
+    };
+    std::stable_sort(order, order + tb.n, [&](int a, int b) { return depth(a) > depth(b); });
+    for (int oi = 0; oi < tb.n; ++oi) {
+      const int i = oi;
+      lic_reduce_job q = jobs[base + order[oi]];
       if (!q.src || !q.dst || q.splitk <= 0 || q.Cn <= 0 || (q.epilogue == LIC_REDUCE_EPI_REPARAM && !q.param)) return LIC_ERR_INVALID;
       if (q.kind == LIC_REDUCE_SLABS) {
         if (q.ntaps <= 0 || q.Cm <= 0 || q.mdiv < 0 || q.ndiv < 0) return LIC_ERR_INVALID;
