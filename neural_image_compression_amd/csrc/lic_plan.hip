@@ -24,6 +24,7 @@
 // eager step bit for bit.  Nothing here knows the model: any capture of kernel, memset, memcpy and empty nodes on
 // one device works.
 #include "lic_common.h"
+#include <cstring>
 
 #include <stdio.h>
 #include <stdlib.h>
@@ -228,6 +229,17 @@ LIC_EXPORT int lic_plan_create(void* hip_graph, lic_plan** out) {
         int pick = -1;
         for (int c = 0; c < NS; ++c)
           if (c != avoid && (pick < 0 || tail[c] < tail[pick])) pick = c;   // (-1 = never used sorts first)
+        // the batched reduction forked off beside a chain (functional.flush_point) is a filler: it goes to the LAST stream --
+        // the callers give the first extra stream a high priority for the chain it carries, and a high-priority launch
+        // of ~6000 blocks takes the chip from the other chain's small launches (a 4 MB cast measured 69 us beside it)
+        static const bool filler_last = [] {
+          const char* e = getenv("LIC_PLAN_REDUCE_LAST");
+          return !(e && e[0] == '0');
+        }();
+        if (filler_last && avoid != NS - 1 && p->ops[k].type == hipGraphNodeTypeKernel) {
+          const char* nm = hipKernelNameRefByPtr(p->ops[k].kp.func, nullptr);
+          if (nm && strstr(nm, "reduce_batch_kernel")) pick = NS - 1;
+        }
         s = pick;
       }
     }
