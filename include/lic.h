@@ -253,7 +253,7 @@ int lic_factorized_channel_logits(const float* fe_params, int32_t ch, const floa
 
 /* ---- rate-distortion loss (RateDistortionLoss.py:5-49) ---------------------------------------
  * Per-image element counts ny, nz, nx; images are contiguous blocks (layout-agnostic sums).
- * out[0..8] = loss, bpp_y, bpp_z, bpp_total, mse, psnr, bits_y, bits_z, bits_total;
+ * out[0..8] = loss, bpp_y, bpp_z, bpp_total, mse, psnr, bits_y, bits_z, bits_total; out[9..15] = 0 (every slot is written);
  * out[16 .. 16+B) = mse_per_image; out[16+B .. 16+2B) = psnr_per_image. */
 size_t lic_rd_loss_workspace_bytes(int32_t B);
 int lic_rd_loss_fwd(const float* logp_y, int64_t ny, const float* logp_z, int64_t nz,

@@ -946,6 +946,8 @@ __global__ __launch_bounds__(64) void rd_final_kernel(const double* partial, int
     out[6] = (float)(sby / B);
     out[7] = (float)(sbz / B);
     out[8] = (float)((sby + sbz) / B);
+#pragma unroll
+    for (int k = 9; k < 16; ++k) out[k] = 0.0f;   // (unused slots: the caller need not clear the buffer first)
   }
 }
 LIC_EXPORT size_t lic_rd_loss_workspace_bytes(int32_t B) {
@@ -975,11 +977,28 @@ LIC_EXPORT int lic_rd_loss_bwd(const float* x_hat, const float* x, int64_t ny, i
   const float ln2 = 0.693147180559945309f;
   const float ky = -1.0f / (ln2 * (float)num_pixels * (float)B);
   const float kx = lambda_rd * (255.0f * 255.0f) * 2.0f / ((float)nx * (float)B);
+  const long n = nx * B;
+  if (al16(x_hat) && al16(x) && al16(dx_hat) && n % 4 == 0 && ny >= 0 && nz >= 0) {
+    // one launch for the three gradients (they were three: the two constant fills are 1 M and 65 K elements behind a
+    // launch each, in the one segment of a step where both streams wait for the loss): index ranges [0, n/4) image
+    // gradient, 16 bytes per lane; then dlogp_y; then dlogp_z -- the same expressions, bit for bit
+    const long n4 = n / 4, e1 = n4 + ny * B, e2 = e1 + nz * B;
+    return ew_launch(e2, stream, [=] __device__(long i) {
+      if (i < n4) {
+        const f32x4 a = reinterpret_cast<const f32x4*>(x_hat)[i], c = reinterpret_cast<const f32x4*>(x)[i];
+        const float k = gl[0] * kx;
+        reinterpret_cast<f32x4*>(dx_hat)[i] = (a - c) * k;
+      } else if (i < e1) {
+        dlogp_y[i - n4] = gl[0] * ky;
+      } else {
+        dlogp_z[i - e1] = gl[0] * ky;
+      }
+    });
+  }
   int rc = ew_launch(ny * B, stream, [=] __device__(long i) { dlogp_y[i] = gl[0] * ky; });
   if (rc != LIC_OK) return rc;
   rc = ew_launch(nz * B, stream, [=] __device__(long i) { dlogp_z[i] = gl[0] * ky; });
   if (rc != LIC_OK) return rc;
-  const long n = nx * B;
   return ew_launch_vec(
       n, al16(x_hat) && al16(x) && al16(dx_hat), stream,
       [=] __device__(long i) {

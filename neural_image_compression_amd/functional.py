@@ -1270,7 +1270,7 @@ class _RdLossFn(torch.autograd.Function):
         xh, xx = _nhwc(x_hat), _nhwc(x)
         B = xx.shape[0]
         lib = L.load()
-        out = torch.zeros((16 + 2 * B,), device=x.device, dtype=torch.float32)
+        out = torch.empty((16 + 2 * B,), device=x.device, dtype=torch.float32)   # (lic_rd_loss_fwd writes every slot)
         nbytes = lib.lic_rd_loss_workspace_bytes(B)
         ws = torch.empty((nbytes + 3) // 4, device=x.device, dtype=torch.float32)
         num_pixels = xx.shape[1] * xx.shape[2]
@@ -1284,6 +1284,7 @@ class _RdLossFn(torch.autograd.Function):
         # plan -- plan.StepPlan -- cannot read back from the captured graph)
         loss = out.new_empty(()).set_(out.untyped_storage(), out.storage_offset(), ())
         ctx.mark_non_differentiable(out)
+        ctx.set_materialize_grads(False)   # (no zero-fill launch for the buffer's never-used gradient)
         return out, loss
 
     @staticmethod
@@ -1291,6 +1292,8 @@ class _RdLossFn(torch.autograd.Function):
         xh, xx = ctx.saved_tensors
         shy, shz, lam, num_pixels = ctx.cfg
         B = xx.shape[0]
+        if gloss is None:
+            return None, None, None, None, None
         gl = gloss.reshape(1).contiguous()  # only `loss` carries gradient
         dly = torch.empty(shy, device=xx.device, dtype=torch.float32)
         dlz = torch.empty(shz, device=xx.device, dtype=torch.float32)

@@ -46,6 +46,7 @@ class StepPlan:
         self._plan = C.c_void_p()
         self._lib = L.load()
         dev = example.device
+        self._one = torch.ones((), device=dev, dtype=torch.float32)
         gen_state = torch.cuda.get_rng_state(dev)   # (the probe and the warm-up draw noise: restored below)
         with torch.no_grad():
             probe = model.analysis_hyperprior(self.x, training=True) if hasattr(model, "analysis_hyperprior") \
@@ -120,7 +121,7 @@ class StepPlan:
         try:
             out = self.model(self.x, noise=self.noise)
             res = self.loss_fn(out, self.x, self.lam, sync=False)
-            res["loss"].backward()
+            res["loss"].backward(self._one)   # (a resident 1.0: `backward()` alone launches a fill for it every step)
         finally:
             F_.EARLY_FLUSH = early
         return out, res
