@@ -77,6 +77,9 @@ _PENDING_LATE = []   # tensors of an EARLY flush on another stream: released at 
 # 9729 / 9642 img/s at config 3, same box); for the eager, host-paced step no gain could be measured (its run-to-run
 # spread on a shared host is larger than the effect), so it keeps the single flush at the end of the pass
 EARLY_FLUSH = os.environ.get("LIC_EARLY_FLUSH", "0") == "1"
+# True while plan.StepPlan runs the step it records (and its warm-up steps): stream placements that pay replayed but not
+# host-paced (models.py: the factorised likelihood on the second stream)
+PLAN_RECORDING = False
 
 
 def flush_reductions(early_on=None):

@@ -118,12 +118,14 @@ class StepPlan:
         # (recorded steps launch the decoder's and the latent side's pending reductions as soon as dL/dy is complete, on the
         # second stream: functional.flush_point -- worth ~1 % replayed, harmful eager)
         early, F_.EARLY_FLUSH = F_.EARLY_FLUSH, os.environ.get("LIC_EARLY_FLUSH", "1") != "0"
+        F_.PLAN_RECORDING = True
         try:
             out = self.model(self.x, noise=self.noise)
             res = self.loss_fn(out, self.x, self.lam, sync=False)
             res["loss"].backward(self._one)   # (a resident 1.0: `backward()` alone launches a fill for it every step)
         finally:
             F_.EARLY_FLUSH = early
+            F_.PLAN_RECORDING = False
         return out, res
 
     def _eager_body(self):
